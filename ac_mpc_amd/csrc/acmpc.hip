@@ -1,0 +1,602 @@
+// acmpc.hip — host side of libacmpc.so: context, workspace, kernel launches, the C ABI of
+// include/acmpc.h.  Device code is in acmpc_kernels.hpp.  gfx950 only; no CPU backend.
+#include "acmpc_kernels.hpp"
+#include "../../include/acmpc.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace acmpc;
+
+#define ACMPC_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+constexpr int kMaxLds = 160 * 1024;
+constexpr int kLdsReserve = 1024;       // static LDS some kernels declare besides the tables
+
+char g_init_error[512] = "no error";
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;     // elements
+};
+
+}  // namespace
+
+struct acmpc_ctx {
+  int device = -1;
+  int n_cu = 0;
+  char err[512];
+
+  // product table
+  int32_t n_products = 0;
+  int32_t p_pad = 0;
+  bool price_fits32 = false;
+  DevBuf<int64_t> d_price;
+
+  // workspace
+  DevBuf<uint32_t> d_prod_slab;
+  DevBuf<unsigned long long> d_prod_carry;
+  DevBuf<int32_t> d_rec_id;
+  DevBuf<int64_t> d_rec_sum;
+  DevBuf<uint32_t> d_cust_slab;
+  DevBuf<unsigned long long> d_cust_carry;
+  uint32_t* d_status = nullptr;
+  bool carry_dirty = false;     // a launch failed half way: clear the carries before the next call
+
+  // staging buffers of the host-pointer entry point
+  DevBuf<int32_t> s_order_id, s_product_idx, s_qty, s_order_customer;
+  DevBuf<int64_t> s_order_total, s_product_qty, s_customer_total;
+  DevBuf<int64_t> s_synth_off;
+  DevBuf<unsigned long long> s_synth_cdf;
+
+  // tuning (environment overrides, read once)
+  int k1_threads = 1024;
+  int k1_blocks_per_cu = 1;
+  int k2_threads = 1024;
+  int force_global_tables = 0;
+
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[ACMPC_N_KERNELS + 1] = {};
+  bool ev_recorded = false;
+};
+
+namespace {
+
+int fail(acmpc_ctx* ctx, int code, const char* fmt, ...) {
+  char* dst = ctx ? ctx->err : g_init_error;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(dst, 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                                      \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? ACMPC_E_NOMEM : ACMPC_E_HIP, "%s failed: %s", \
+                  #call, hipGetErrorString(e_));                                               \
+  } while (0)
+
+template <typename T>
+int ensure(acmpc_ctx* ctx, DevBuf<T>& b, size_t n, bool zero_new = false) {
+  if (n == 0) n = 1;
+  if (b.cap >= n) return ACMPC_OK;
+  if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+  HIPCHK(ctx, hipMalloc((void**)&b.p, n * sizeof(T)));
+  b.cap = n;
+  if (zero_new) HIPCHK(ctx, hipMemset(b.p, 0, n * sizeof(T)));
+  return ACMPC_OK;
+}
+
+template <typename T>
+void release(DevBuf<T>& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename K>
+int set_dyn_lds(acmpc_ctx* ctx, K kernel, size_t bytes) {
+  HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return ACMPC_OK;
+}
+
+struct LinesPlan {
+  bool lds_tables;
+  bool price32;
+  size_t lds_bytes;
+  int threads, blocks, waves_per_block;
+  int64_t n_tiles, tiles_per_wave;
+  int n_active_waves;
+};
+
+int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p) {
+  const size_t need32 = (size_t)ctx->p_pad * 8, need64 = (size_t)ctx->p_pad * 12;
+  p->price32 = ctx->price_fits32;
+  p->lds_bytes = p->price32 ? need32 : need64;
+  p->lds_tables = !ctx->force_global_tables && p->lds_bytes + kLdsReserve <= (size_t)kMaxLds;
+  if (!p->lds_tables) { p->lds_bytes = 0; p->price32 = false; }
+  p->threads = ctx->k1_threads;
+  p->waves_per_block = p->threads / kWave;
+  int bpc = ctx->k1_blocks_per_cu;
+  if (p->lds_tables) {
+    const int fit = (int)((size_t)kMaxLds / (p->lds_bytes + kLdsReserve));
+    bpc = std::max(1, std::min(bpc, fit));
+  }
+  bpc = std::max(1, std::min(bpc, 2048 / p->threads));
+  int max_blocks = ctx->n_cu * bpc;
+  max_blocks = std::min(max_blocks, kMaxWavesTotal / p->waves_per_block);
+  p->n_tiles = (n_lines + kTile - 1) / kTile;
+  const int64_t max_waves = (int64_t)max_blocks * p->waves_per_block;
+  p->tiles_per_wave = std::max<int64_t>(1, (p->n_tiles + max_waves - 1) / max_waves);
+  p->n_active_waves = (int)((p->n_tiles + p->tiles_per_wave - 1) / p->tiles_per_wave);
+  p->blocks = std::max(1, (p->n_active_waves + p->waves_per_block - 1) / p->waves_per_block);
+  return ACMPC_OK;
+}
+
+struct CustPlan {
+  bool lds_tables;
+  int n_ranges, span, n_streams, blocks, threads;
+  size_t lds_bytes;
+  int64_t n_tiles, tiles_per_stream;
+  int c_pad;
+};
+
+void plan_customers(const acmpc_ctx* ctx, int64_t n_orders, int32_t n_customers, CustPlan* p) {
+  p->threads = ctx->k2_threads;
+  const int slots = std::max(1, ctx->n_cu / 8);             // workgroups per XCD label, one per CU
+  const int max_span = (128 * 1024) / 4;                    // 128 KiB of 32-bit partials
+  int r = 1;
+  while ((int64_t)r * max_span < n_customers && r < 64) r <<= 1;
+  p->lds_tables = !ctx->force_global_tables && r <= slots && (int64_t)r * max_span >= n_customers;
+  p->n_tiles = (n_orders + kTile - 1) / kTile;
+  p->c_pad = (n_customers + 3) & ~3;
+  if (!p->lds_tables) {
+    p->n_ranges = 1;
+    p->span = n_customers;
+    p->lds_bytes = 0;
+    const int64_t want = std::max<int64_t>(1, (p->n_tiles + 63) / 64);
+    const int groups = (int)std::min<int64_t>(slots, want);
+    p->n_streams = 8 * groups;
+  } else {
+    p->n_ranges = r;
+    p->span = (n_customers + r - 1) / r;
+    p->span = (p->span + 3) & ~3;
+    p->lds_bytes = (size_t)p->span * 4;
+    const int max_groups = std::max(1, slots / r);
+    // small inputs: fewer streams, so that every stream still has a few tiles per wave
+    const int64_t want = std::max<int64_t>(1, (p->n_tiles + 8 * 32 - 1) / (8 * 32));
+    const int groups = (int)std::min<int64_t>(max_groups, want);
+    p->n_streams = 8 * groups;
+  }
+  p->blocks = p->n_streams * p->n_ranges;
+  p->tiles_per_stream = std::max<int64_t>(1, (p->n_tiles + p->n_streams - 1) / p->n_streams);
+}
+
+int clear_carries(acmpc_ctx* ctx, hipStream_t st) {
+  if (ctx->d_prod_carry.p)
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_prod_carry.p, 0, ctx->d_prod_carry.cap * 8, st));
+  if (ctx->d_cust_carry.p)
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_cust_carry.p, 0, ctx->d_cust_carry.cap * 8, st));
+  ctx->carry_dirty = false;
+  return ACMPC_OK;
+}
+
+template <typename PriceT, bool kLds>
+int launch_lines(acmpc_ctx* ctx, const LinesPlan& pl, const LinesArgs& a, hipStream_t st) {
+  auto kern = k_lines<PriceT, kLds>;
+  if (pl.lds_bytes > 48 * 1024) {
+    int rc = set_dyn_lds(ctx, kern, pl.lds_bytes);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(pl.threads), pl.lds_bytes, st, a);
+  HIPCHK(ctx, hipGetLastError());
+  return ACMPC_OK;
+}
+
+int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32_t* d_product_idx,
+                          const int32_t* d_qty, int64_t n_lines, const int32_t* d_order_customer,
+                          int64_t n_orders, int32_t base, int32_t n_customers, int64_t* d_tot,
+                          int64_t* d_pq, int64_t* d_ct, hipStream_t st) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_aggregate_device: null context");
+  if (ctx->n_products <= 0) return fail(ctx, ACMPC_E_STATE, "acmpc_set_products has not been called");
+  if (n_lines < 0 || n_orders < 0 || n_customers <= 0)
+    return fail(ctx, ACMPC_E_INVALID, "negative size or n_customers <= 0");
+  if (n_orders > 0x7fffffffll || n_lines > (1ll << 40))
+    return fail(ctx, ACMPC_E_INVALID, "n_orders must fit int32 (order ids are INT, store.sql:98,159)");
+  if ((n_lines > 0 && (!d_order_id || !d_product_idx || !d_qty)) || (n_orders > 0 && (!d_order_customer || !d_tot)) ||
+      !d_pq || !d_ct)
+    return fail(ctx, ACMPC_E_INVALID, "null device pointer");
+  if (n_lines > 0 && n_orders == 0)
+    return fail(ctx, ACMPC_E_INVALID, "n_lines > 0 with n_orders == 0");
+  if (!aligned16(d_order_id) || !aligned16(d_product_idx) || !aligned16(d_qty) ||
+      !aligned16(d_order_customer) || !aligned16(d_tot))
+    return fail(ctx, ACMPC_E_ALIGN, "device columns must be 16-byte aligned");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+
+  const int32_t P = ctx->n_products;
+  if (ctx->carry_dirty) { int rc = clear_carries(ctx, st); if (rc) return rc; }
+
+  if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[0], st));
+
+  // ---- order-line pass ------------------------------------------------------------------
+  LinesPlan lp;
+  plan_lines(ctx, n_lines, &lp);
+  int rc;
+  if (n_lines == 0) {
+    if (n_orders > 0) HIPCHK(ctx, hipMemsetAsync(d_tot, 0, (size_t)n_orders * 8, st));
+    HIPCHK(ctx, hipMemsetAsync(d_pq, 0, (size_t)P * 8, st));
+    if (ctx->profiling) { HIPCHK(ctx, hipEventRecord(ctx->ev[1], st)); HIPCHK(ctx, hipEventRecord(ctx->ev[2], st)); }
+  } else {
+    if ((rc = ensure(ctx, ctx->d_prod_carry, (size_t)ctx->p_pad, true))) return rc;
+    if ((rc = ensure(ctx, ctx->d_rec_id, (size_t)2 * kMaxWavesTotal))) return rc;
+    if ((rc = ensure(ctx, ctx->d_rec_sum, (size_t)2 * kMaxWavesTotal))) return rc;
+    if (lp.lds_tables && (rc = ensure(ctx, ctx->d_prod_slab, (size_t)lp.blocks * ctx->p_pad))) return rc;
+
+    LinesArgs a;
+    a.order_id = d_order_id; a.product_idx = d_product_idx; a.qty = d_qty;
+    a.n_lines = n_lines; a.n_tiles = lp.n_tiles; a.tiles_per_wave = lp.tiles_per_wave;
+    a.base = base; a.n_orders = (int32_t)n_orders;
+    a.price = ctx->d_price.p; a.n_products = P; a.p_pad = ctx->p_pad;
+    a.order_total = d_tot; a.prod_slab = ctx->d_prod_slab.p; a.prod_carry = ctx->d_prod_carry.p;
+    a.rec_id = ctx->d_rec_id.p; a.rec_sum = ctx->d_rec_sum.p; a.status = ctx->d_status;
+
+    ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
+    if (!lp.lds_tables) rc = launch_lines<int64_t, false>(ctx, lp, a, st);
+    else if (lp.price32) rc = launch_lines<int32_t, true>(ctx, lp, a, st);
+    else rc = launch_lines<int64_t, true>(ctx, lp, a, st);
+    if (rc) return rc;
+    if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
+
+    FixArgs f;
+    f.rec_id = ctx->d_rec_id.p; f.rec_sum = ctx->d_rec_sum.p; f.n_rec = 2 * lp.n_active_waves;
+    f.base = base; f.n_orders = (int32_t)n_orders; f.order_total = d_tot; f.status = ctx->d_status;
+    f.prod_slab = ctx->d_prod_slab.p; f.n_slabs = lp.blocks; f.p_pad = ctx->p_pad; f.n_products = P;
+    f.merge_products = lp.lds_tables ? 1 : 0;
+    f.prod_carry = ctx->d_prod_carry.p; f.product_qty = d_pq;
+    const size_t fix_lds = (size_t)kFixThreads * kFixStrip * 12;
+    if ((rc = set_dyn_lds(ctx, k_fixup, fix_lds))) return rc;
+    const int fix_blocks = 1 + (lp.lds_tables ? (P + kMergeProducts - 1) / kMergeProducts : 0);
+    hipLaunchKernelGGL(k_fixup, dim3(fix_blocks), dim3(kFixThreads), fix_lds, st, f);
+    HIPCHK(ctx, hipGetLastError());
+    if (!lp.lds_tables) {
+      hipLaunchKernelGGL(k_move_clear, dim3((P + 255) / 256), dim3(256), 0, st, ctx->d_prod_carry.p, d_pq, P);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
+  }
+
+  // ---- per-customer pass ----------------------------------------------------------------
+  if (n_orders == 0) {
+    HIPCHK(ctx, hipMemsetAsync(d_ct, 0, (size_t)n_customers * 8, st));
+    if (ctx->profiling) { HIPCHK(ctx, hipEventRecord(ctx->ev[3], st)); HIPCHK(ctx, hipEventRecord(ctx->ev[4], st)); }
+  } else {
+    CustPlan cp;
+    plan_customers(ctx, n_orders, n_customers, &cp);
+    if (ctx->d_cust_carry.cap < (size_t)n_customers) {
+      if ((rc = ensure(ctx, ctx->d_cust_carry, (size_t)n_customers, true))) return rc;
+    }
+    if (cp.lds_tables && (rc = ensure(ctx, ctx->d_cust_slab, (size_t)cp.n_streams * cp.c_pad))) return rc;
+    CustArgs c;
+    c.order_customer = d_order_customer; c.order_total = d_tot; c.n_orders = n_orders;
+    c.n_tiles = cp.n_tiles; c.tiles_per_stream = cp.tiles_per_stream;
+    c.n_customers = n_customers; c.c_pad = cp.c_pad; c.span = cp.span; c.n_ranges = cp.n_ranges;
+    c.n_streams = cp.n_streams; c.cust_slab = ctx->d_cust_slab.p; c.cust_carry = ctx->d_cust_carry.p;
+    c.status = ctx->d_status;
+    ctx->carry_dirty = true;
+    if (cp.lds_tables) {
+      if (cp.lds_bytes > 48 * 1024 && (rc = set_dyn_lds(ctx, k_customers<true>, cp.lds_bytes))) return rc;
+      hipLaunchKernelGGL(k_customers<true>, dim3(cp.blocks), dim3(cp.threads), cp.lds_bytes, st, c);
+    } else {
+      hipLaunchKernelGGL(k_customers<false>, dim3(cp.blocks), dim3(cp.threads), 0, st, c);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
+    if (cp.lds_tables) {
+      CustMergeArgs m;
+      m.cust_slab = ctx->d_cust_slab.p; m.n_streams = cp.n_streams; m.c_pad = cp.c_pad;
+      m.n_customers = n_customers; m.cust_carry = ctx->d_cust_carry.p; m.customer_total = d_ct;
+      hipLaunchKernelGGL(k_custmerge, dim3((n_customers + 255) / 256), dim3(256), 0, st, m);
+    } else {
+      hipLaunchKernelGGL(k_move_clear, dim3((n_customers + 255) / 256), dim3(256), 0, st,
+                         ctx->d_cust_carry.p, d_ct, n_customers);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
+  }
+  ctx->carry_dirty = false;
+  if (ctx->profiling) ctx->ev_recorded = true;
+  return ACMPC_OK;
+}
+
+// ---- synthetic data, host part ---------------------------------------------------------
+
+int synth_check(acmpc_ctx* ctx, const acmpc_synth_cfg* c) {
+  if (!c) return fail(ctx, ACMPC_E_INVALID, "null synth config");
+  if (c->n_lines_total < 0 || c->n_products <= 0 || c->n_customers <= 0 || c->world <= 0 || c->rank < 0 ||
+      c->rank >= c->world)
+    return fail(ctx, ACMPC_E_INVALID, "bad synth config");
+  return ACMPC_OK;
+}
+
+inline int synth_len(int64_t o) { return 1 + (int)(synth_hash(kSeedLen, (unsigned long long)o) % 7ull); }
+
+int64_t synth_count_orders(int64_t n_lines_total) {
+  int64_t acc = 0, o = 0;
+  while (acc < n_lines_total) { acc += synth_len(o); ++o; }
+  return o;
+}
+
+// Line offsets of orders lo and hi, and (optionally) of every 1024th order from lo on.
+void synth_offsets(int64_t n_lines_total, int64_t lo, int64_t hi, int64_t* line_lo, int64_t* line_hi,
+                   std::vector<int64_t>* block_off) {
+  int64_t acc = 0;
+  for (int64_t o = 0; o < hi; ++o) {
+    if (o == lo) *line_lo = acc;
+    if (block_off && o >= lo && ((o - lo) % kSynthOrdersPerBlock) == 0) block_off->push_back(acc);
+    acc += synth_len(o);
+    if (acc > n_lines_total) acc = n_lines_total;
+  }
+  if (lo >= hi) *line_lo = acc;
+  *line_hi = acc;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+
+ACMPC_API const char* acmpc_version(void) { return "acmpc 0.1 gfx950"; }
+
+ACMPC_API const char* acmpc_last_error(const acmpc_ctx* ctx) { return ctx ? ctx->err : g_init_error; }
+
+ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
+  if (!out) return fail(nullptr, ACMPC_E_INVALID, "acmpc_init: null out pointer");
+  *out = nullptr;
+  if (device < 0) return fail(nullptr, ACMPC_E_INVALID, "acmpc_init: device must be >= 0 (there is no CPU backend)");
+  int n = 0;
+  HIPCHK(nullptr, hipGetDeviceCount(&n));
+  if (device >= n) return fail(nullptr, ACMPC_E_INVALID, "acmpc_init: device %d of %d", device, n);
+  HIPCHK(nullptr, hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, ACMPC_E_INVALID, "acmpc_init: device %d is %s, this library is built for gfx950 only",
+                device, prop.gcnArchName);
+  acmpc_ctx* ctx = new (std::nothrow) acmpc_ctx();
+  if (!ctx) return fail(nullptr, ACMPC_E_NOMEM, "acmpc_init: out of host memory");
+  strcpy(ctx->err, "no error");
+  ctx->device = device;
+  ctx->n_cu = prop.multiProcessorCount;
+  ctx->k1_threads = env_int("ACMPC_K1_THREADS", 1024);
+  if (ctx->k1_threads != 256 && ctx->k1_threads != 512 && ctx->k1_threads != 1024) ctx->k1_threads = 1024;
+  ctx->k1_blocks_per_cu = std::max(1, env_int("ACMPC_K1_BPC", 1));
+  ctx->k2_threads = env_int("ACMPC_K2_THREADS", 1024);
+  if (ctx->k2_threads != 256 && ctx->k2_threads != 512 && ctx->k2_threads != 1024) ctx->k2_threads = 1024;
+  ctx->force_global_tables = env_int("ACMPC_FORCE_GLOBAL_TABLES", 0);
+  hipError_t e = hipMalloc((void**)&ctx->d_status, sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(ctx->d_status, 0, sizeof(uint32_t));
+  for (int i = 0; i <= ACMPC_N_KERNELS && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
+  if (e != hipSuccess) {
+    fail(nullptr, ACMPC_E_HIP, "acmpc_init: %s", hipGetErrorString(e));
+    acmpc_destroy(ctx);
+    return ACMPC_E_HIP;
+  }
+  *out = ctx;
+  return ACMPC_OK;
+}
+
+ACMPC_API void acmpc_destroy(acmpc_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  release(ctx->d_price); release(ctx->d_prod_slab); release(ctx->d_prod_carry);
+  release(ctx->d_rec_id); release(ctx->d_rec_sum); release(ctx->d_cust_slab); release(ctx->d_cust_carry);
+  release(ctx->s_order_id); release(ctx->s_product_idx); release(ctx->s_qty); release(ctx->s_order_customer);
+  release(ctx->s_order_total); release(ctx->s_product_qty); release(ctx->s_customer_total);
+  release(ctx->s_synth_off); release(ctx->s_synth_cdf);
+  if (ctx->d_status) (void)hipFree(ctx->d_status);
+  for (int i = 0; i <= ACMPC_N_KERNELS; ++i)
+    if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  delete ctx;
+}
+
+ACMPC_API int acmpc_set_products(acmpc_ctx* ctx, const int64_t* price_cents, int32_t n_products) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_set_products: null context");
+  if (!price_cents || n_products <= 0) return fail(ctx, ACMPC_E_INVALID, "acmpc_set_products: empty product table");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());          // nothing may still be reading the old table
+  int rc = ensure(ctx, ctx->d_price, (size_t)n_products);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpy(ctx->d_price.p, price_cents, (size_t)n_products * 8, hipMemcpyHostToDevice));
+  bool fits = true;
+  for (int32_t i = 0; i < n_products; ++i)
+    if (price_cents[i] < INT32_MIN || price_cents[i] > INT32_MAX) { fits = false; break; }
+  ctx->price_fits32 = fits;
+  ctx->n_products = n_products;
+  ctx->p_pad = (n_products + 3) & ~3;
+  // the carry workspace is indexed by product: start it clean at the new size
+  release(ctx->d_prod_carry);
+  if ((rc = ensure(ctx, ctx->d_prod_carry, (size_t)ctx->p_pad, true))) return rc;
+  return ACMPC_OK;
+}
+
+ACMPC_API int acmpc_aggregate_device(acmpc_ctx* ctx, const int32_t* d_order_id, const int32_t* d_product_idx,
+                                     const int32_t* d_qty, int64_t n_lines, const int32_t* d_order_customer,
+                                     int64_t n_orders, int32_t order_id_base, int32_t n_customers,
+                                     int64_t* d_out_order_total_cents, int64_t* d_out_product_qty,
+                                     int64_t* d_out_customer_total_cents, void* hip_stream) {
+  return aggregate_device_impl(ctx, d_order_id, d_product_idx, d_qty, n_lines, d_order_customer, n_orders,
+                               order_id_base, n_customers, d_out_order_total_cents, d_out_product_qty,
+                               d_out_customer_total_cents, (hipStream_t)hip_stream);
+}
+
+ACMPC_API int acmpc_status(acmpc_ctx* ctx, void* hip_stream, uint32_t* flags) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_status: null context");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  uint32_t f = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&f, ctx->d_status, sizeof(f), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(f), st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  if (flags) *flags = f;
+  if (f)
+    return fail(ctx, ACMPC_E_DATA, "data contract broken:%s%s%s",
+                (f & ACMPC_ST_ORDER_RANGE) ? " order_id outside [base, base+M);" : "",
+                (f & ACMPC_ST_ORDER_UNSORTED) ? " order_id not non-decreasing;" : "",
+                (f & ACMPC_ST_CUSTOMER_RANGE) ? " order_customer outside [0, C);" : "");
+  return ACMPC_OK;
+}
+
+ACMPC_API int acmpc_aggregate(acmpc_ctx* ctx, const int32_t* order_id, const int32_t* product_idx,
+                              const int32_t* qty, int64_t n_lines, const int32_t* order_customer,
+                              int64_t n_orders, int32_t order_id_base, int32_t n_customers,
+                              int64_t* out_order_total_cents, int64_t* out_product_qty,
+                              int64_t* out_customer_total_cents) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_aggregate: null context");
+  if (ctx->n_products <= 0) return fail(ctx, ACMPC_E_STATE, "acmpc_set_products has not been called");
+  if (n_lines < 0 || n_orders < 0 || n_customers <= 0) return fail(ctx, ACMPC_E_INVALID, "negative size or n_customers <= 0");
+  if ((n_lines > 0 && (!order_id || !product_idx || !qty)) || (n_orders > 0 && (!order_customer || !out_order_total_cents)) ||
+      !out_product_qty || !out_customer_total_cents)
+    return fail(ctx, ACMPC_E_INVALID, "null host pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int32_t P = ctx->n_products;
+  int rc;
+  if ((rc = ensure(ctx, ctx->s_order_id, (size_t)n_lines))) return rc;
+  if ((rc = ensure(ctx, ctx->s_product_idx, (size_t)n_lines))) return rc;
+  if ((rc = ensure(ctx, ctx->s_qty, (size_t)n_lines))) return rc;
+  if ((rc = ensure(ctx, ctx->s_order_customer, (size_t)n_orders))) return rc;
+  if ((rc = ensure(ctx, ctx->s_order_total, (size_t)n_orders))) return rc;
+  if ((rc = ensure(ctx, ctx->s_product_qty, (size_t)P))) return rc;
+  if ((rc = ensure(ctx, ctx->s_customer_total, (size_t)n_customers))) return rc;
+  hipStream_t st = nullptr;
+  if (n_lines > 0) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->s_order_id.p, order_id, (size_t)n_lines * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->s_product_idx.p, product_idx, (size_t)n_lines * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->s_qty.p, qty, (size_t)n_lines * 4, hipMemcpyHostToDevice, st));
+  }
+  if (n_orders > 0)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->s_order_customer.p, order_customer, (size_t)n_orders * 4, hipMemcpyHostToDevice, st));
+  rc = aggregate_device_impl(ctx, ctx->s_order_id.p, ctx->s_product_idx.p, ctx->s_qty.p, n_lines,
+                             ctx->s_order_customer.p, n_orders, order_id_base, n_customers, ctx->s_order_total.p,
+                             ctx->s_product_qty.p, ctx->s_customer_total.p, st);
+  if (rc) return rc;
+  if (n_orders > 0)
+    HIPCHK(ctx, hipMemcpyAsync(out_order_total_cents, ctx->s_order_total.p, (size_t)n_orders * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipMemcpyAsync(out_product_qty, ctx->s_product_qty.p, (size_t)P * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipMemcpyAsync(out_customer_total_cents, ctx->s_customer_total.p, (size_t)n_customers * 8, hipMemcpyDeviceToHost, st));
+  uint32_t flags = 0;
+  return acmpc_status(ctx, st, &flags);
+}
+
+ACMPC_API int acmpc_set_profiling(acmpc_ctx* ctx, int enabled) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_set_profiling: null context");
+  ctx->profiling = enabled != 0;
+  ctx->ev_recorded = false;
+  return ACMPC_OK;
+}
+
+ACMPC_API int acmpc_last_kernel_ms(acmpc_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return fail(ctx, ACMPC_E_INVALID, "acmpc_last_kernel_ms: null argument");
+  if (!ctx->profiling || !ctx->ev_recorded)
+    return fail(ctx, ACMPC_E_STATE, "no profiled acmpc_aggregate_device call to report");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipEventSynchronize(ctx->ev[ACMPC_N_KERNELS]));
+  for (int i = 0; i < ACMPC_N_KERNELS; ++i) HIPCHK(ctx, hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
+  return ACMPC_OK;
+}
+
+ACMPC_API int acmpc_lines_geometry(acmpc_ctx* ctx, int32_t* n_workgroups, int32_t* waves_per_workgroup) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_lines_geometry: null context");
+  LinesPlan lp;
+  plan_lines(ctx, (int64_t)1 << 40, &lp);
+  if (n_workgroups) *n_workgroups = lp.blocks;
+  if (waves_per_workgroup) *waves_per_workgroup = lp.waves_per_block;
+  return ACMPC_OK;
+}
+
+// ---- synthetic data ----------------------------------------------------------------------
+
+ACMPC_API int acmpc_synth_plan(const acmpc_synth_cfg* cfg, acmpc_synth_shard* out) {
+  int rc = synth_check(nullptr, cfg);
+  if (rc) return rc;
+  if (!out) return fail(nullptr, ACMPC_E_INVALID, "acmpc_synth_plan: null out");
+  const int64_t M = synth_count_orders(cfg->n_lines_total);
+  out->n_orders_total = M;
+  out->order_lo = (int64_t)(((__int128)M * cfg->rank) / cfg->world);
+  out->order_hi = (int64_t)(((__int128)M * (cfg->rank + 1)) / cfg->world);
+  synth_offsets(cfg->n_lines_total, out->order_lo, out->order_hi, &out->line_lo, &out->line_hi, nullptr);
+  return ACMPC_OK;
+}
+
+ACMPC_API int acmpc_synth_prices(const acmpc_synth_cfg* cfg, int64_t* price_cents) {
+  int rc = synth_check(nullptr, cfg);
+  if (rc) return rc;
+  if (!price_cents) return fail(nullptr, ACMPC_E_INVALID, "acmpc_synth_prices: null out");
+  static const int64_t seed_rows[3] = {25000, 45000, 150000};   // store.sql:126-128
+  for (int32_t p = 0; p < cfg->n_products; ++p)
+    price_cents[p] = p < 3 ? seed_rows[p] : 1 + (int64_t)(synth_hash(kSeedPrice, (unsigned long long)p) % 500000ull);
+  return ACMPC_OK;
+}
+
+ACMPC_API int acmpc_synth_generate_device(acmpc_ctx* ctx, const acmpc_synth_cfg* cfg, int32_t* d_order_id,
+                                          int32_t* d_product_idx, int32_t* d_qty, int32_t* d_order_customer,
+                                          void* hip_stream) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_synth_generate_device: null context");
+  int rc = synth_check(ctx, cfg);
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int64_t M = synth_count_orders(cfg->n_lines_total);
+  const int64_t lo = (int64_t)(((__int128)M * cfg->rank) / cfg->world);
+  const int64_t hi = (int64_t)(((__int128)M * (cfg->rank + 1)) / cfg->world);
+  if (hi <= lo) return ACMPC_OK;
+  if (!d_order_id || !d_product_idx || !d_qty || !d_order_customer)
+    return fail(ctx, ACMPC_E_INVALID, "acmpc_synth_generate_device: null device pointer");
+  std::vector<int64_t> off;
+  int64_t line_lo = 0, line_hi = 0;
+  synth_offsets(cfg->n_lines_total, lo, hi, &line_lo, &line_hi, &off);
+  if ((rc = ensure(ctx, ctx->s_synth_off, off.size()))) return rc;
+  // the previous generate call may still be reading the staging buffers
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  HIPCHK(ctx, hipMemcpy(ctx->s_synth_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+  SynthArgs a;
+  a.n_lines_total = cfg->n_lines_total; a.order_lo = lo; a.order_hi = hi; a.line_lo = line_lo;
+  a.block_line_off = ctx->s_synth_off.p; a.cdf = nullptr; a.wtot = 0;
+  a.n_products = cfg->n_products; a.n_customers = cfg->n_customers; a.base = cfg->order_id_base;
+  a.qty_mode = cfg->qty_mode;
+  a.order_id = d_order_id; a.product_idx = d_product_idx; a.qty = d_qty; a.order_customer = d_order_customer;
+  if (cfg->zipf) {
+    std::vector<unsigned long long> cdf((size_t)cfg->n_products);
+    unsigned long long w = 0;
+    for (int32_t k = 0; k < cfg->n_products; ++k) { w += (1ull << 32) / (unsigned long long)(k + 1); cdf[k] = w; }
+    if ((rc = ensure(ctx, ctx->s_synth_cdf, cdf.size()))) return rc;
+    HIPCHK(ctx, hipMemcpy(ctx->s_synth_cdf.p, cdf.data(), cdf.size() * 8, hipMemcpyHostToDevice));
+    a.cdf = ctx->s_synth_cdf.p;
+    a.wtot = w;
+  }
+  const int blocks = (int)((hi - lo + kSynthOrdersPerBlock - 1) / kSynthOrdersPerBlock);
+  hipLaunchKernelGGL(k_synth, dim3(blocks), dim3(kSynthOrdersPerBlock), 0, st, a);
+  HIPCHK(ctx, hipGetLastError());
+  return ACMPC_OK;
+}

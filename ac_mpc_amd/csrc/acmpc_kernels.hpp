@@ -1,0 +1,600 @@
+// acmpc_kernels.hpp — gfx950 (MI355X, CDNA4) device code of the checkout-aggregation engine.
+//
+// Data layout in HBM (all columns are plain dense arrays):
+//   order_id[N], product_idx[N], qty[N]   int32   the `detalle` table (store.sql:97-101), rows of
+//                                                  one order contiguous, order ids non-decreasing
+//   order_customer[M]                      int32   venta.NIT as a dictionary index (store.sql:161)
+//   price_cents[P]                         int64   producto.Precio in cents (store.sql:113)
+//   order_total_cents[M], product_qty[P], customer_total_cents[C]   int64 outputs
+//
+// Kernels (all HBM-bandwidth bound; there is no dense contraction anywhere, so no MFMA):
+//   k_lines      one pass over the three line columns (12 B/line read, 8 B/order written).
+//                One workgroup per CU keeps the price table and a private stock-delta
+//                histogram in LDS; every WAVE owns a contiguous run of 256-line tiles and
+//                carries the open order from tile to tile in registers, so the main loop has
+//                no workgroup barrier.
+//   k_fixup      block 0 resolves the orders cut by a wave boundary (two records per wave);
+//                the other blocks merge the per-workgroup histograms.
+//   k_customers  per-order pass (4 B + 8 B read per order): customer ranges are split over
+//                sibling workgroups that read the same orders (from L2) and each keep their
+//                range of partial sums in LDS.
+//   k_custmerge  merges the per-stream customer partials.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace acmpc {
+
+constexpr int kWave = 64;
+constexpr int kLinesPerLane = 4;                  // one 16-byte load per column per lane
+constexpr int kTile = kWave * kLinesPerLane;      // 256 lines (or orders) per wave-tile
+constexpr int kMaxWavesTotal = 4096;              // k_lines waves; two records each for k_fixup
+constexpr int kFixThreads = 1024;
+constexpr int kFixStrip = 8;                      // records per thread in k_fixup block 0
+constexpr int kMergeProducts = 64;                // products per merge block in k_fixup
+
+constexpr uint32_t kStOrderRange = 1u, kStUnsorted = 2u, kStCustomerRange = 4u;
+
+struct LinesArgs {
+  const int32_t* order_id;
+  const int32_t* product_idx;
+  const int32_t* qty;
+  int64_t n_lines;
+  int64_t n_tiles;          // ceil(n_lines / 256)
+  int64_t tiles_per_wave;
+  int32_t base;             // order_id_base
+  int32_t n_orders;         // M
+  const int64_t* price;     // [P] device
+  int32_t n_products;
+  int32_t p_pad;            // P rounded up to a multiple of 4
+  int64_t* order_total;     // [M]
+  uint32_t* prod_slab;      // [gridDim.x][p_pad] low words of the per-workgroup stock deltas
+  unsigned long long* prod_carry;   // [P] high-word corrections (LDS mode) / product_qty itself (global mode)
+  int32_t* rec_id;          // [2 * waves]  head/tail order id of every wave
+  int64_t* rec_sum;         // [2 * waves]  head/tail partial sums
+  uint32_t* status;
+};
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
+
+__device__ __forceinline__ long long wave_inclusive_scan(long long v, int lane) {
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    long long t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// Add a sign-extended 32-bit quantity to a 64-bit accumulator that is split into a 32-bit low
+// word in LDS and a (rare) high-word correction in global memory.  Exact modulo 2^64.
+__device__ __forceinline__ void split_add32(uint32_t* lds_lo, unsigned long long* g_hi, int32_t q) {
+  const uint32_t uq = (uint32_t)q;
+  const uint32_t old = atomicAdd(lds_lo, uq);
+  const int32_t carry = ((uint32_t)(old + uq) < old) ? 1 : 0;
+  const int32_t hi = (q >> 31) + carry;
+  if (hi != 0) atomicAdd(g_hi, ((unsigned long long)(long long)hi) << 32);
+}
+
+__device__ __forceinline__ void split_add64(uint32_t* lds_lo, unsigned long long* g_hi, long long v) {
+  const uint32_t lo = (uint32_t)v;
+  const uint32_t old = atomicAdd(lds_lo, lo);
+  const long long carry = ((uint32_t)(old + lo) < old) ? 1 : 0;
+  const long long hi = (v >> 32) + carry;
+  if (hi != 0) atomicAdd(g_hi, ((unsigned long long)hi) << 32);
+}
+
+// Zero order_total for the order ids strictly between a and b (exclusive), all 64 lanes helping.
+__device__ __forceinline__ void wave_fill_gap(const LinesArgs& a, int ida, int idb, int lane) {
+  for (long long k = (long long)ida + 1 + lane; k < (long long)idb; k += kWave) {
+    const uint32_t idx = (uint32_t)((int)k) - (uint32_t)a.base;
+    if (idx < (uint32_t)a.n_orders) a.order_total[idx] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_lines
+// ---------------------------------------------------------------------------------------------
+template <typename PriceT, bool kLdsTables>
+__global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  PriceT* s_price = reinterpret_cast<PriceT*>(smem);
+  uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + (size_t)a.p_pad * sizeof(PriceT));
+
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const int waves_per_block = (int)(blockDim.x >> 6);
+  const int P = a.n_products;
+
+  if (kLdsTables) {
+    for (int i = (int)threadIdx.x; i < P; i += (int)blockDim.x) {
+      s_price[i] = (PriceT)a.price[i];
+      s_hist[i] = 0u;
+    }
+    __syncthreads();
+  }
+
+  const long long g = (long long)blockIdx.x * waves_per_block + wave;   // global wave index
+  const long long t0 = g * a.tiles_per_wave;
+  long long t1 = t0 + a.tiles_per_wave;
+  if (t1 > a.n_tiles) t1 = a.n_tiles;
+
+  if (t0 < t1) {
+    const long long n_full = a.n_lines / kTile;      // tiles [0, n_full) are complete
+    uint32_t st = 0;
+    int carry_id = a.order_id[t0 * kTile];          // the wave's run starts inside this order
+    long long carry_sum = 0;
+    bool first_open = true;                          // no order has closed yet in this run
+    const int head_id = carry_id;
+    long long head_sum = 0;
+
+    auto load_tile = [&](long long t, int4& vid, int4& vpr, int4& vq) {
+      const long long l0 = t * kTile + (long long)lane * kLinesPerLane;
+      if (t < n_full) {
+        vid = *reinterpret_cast<const int4*>(a.order_id + l0);
+        vpr = *reinterpret_cast<const int4*>(a.product_idx + l0);
+        vq = *reinterpret_cast<const int4*>(a.qty + l0);
+      } else {
+        // last, partial tile: lines past the end repeat the last order id and carry nothing
+        const int last_id = a.order_id[a.n_lines - 1];
+        int ids[4], prs[4], qs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const long long l = l0 + i;
+          const bool in = l < a.n_lines;
+          ids[i] = in ? a.order_id[l] : last_id;
+          prs[i] = in ? a.product_idx[l] : -1;
+          qs[i] = in ? a.qty[l] : 0;
+        }
+        vid = make_int4(ids[0], ids[1], ids[2], ids[3]);
+        vpr = make_int4(prs[0], prs[1], prs[2], prs[3]);
+        vq = make_int4(qs[0], qs[1], qs[2], qs[3]);
+      }
+    };
+
+    int4 cid, cpr, cq;
+    load_tile(t0, cid, cpr, cq);
+
+    for (long long t = t0; t < t1; ++t) {
+      int4 nid = cid, npr = cpr, nq = cq;
+      if (t + 1 < t1) load_tile(t + 1, nid, npr, nq);       // next tile's loads fly during this tile
+
+      const int ids[4] = {cid.x, cid.y, cid.z, cid.w};
+      const int prs[4] = {cpr.x, cpr.y, cpr.z, cpr.w};
+      const int qs[4] = {cq.x, cq.y, cq.z, cq.w};
+
+      // price gather, line value, stock delta
+      long long v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool valid = (uint32_t)prs[i] < (uint32_t)P;
+        const int pi = valid ? prs[i] : 0;
+        long long price;
+        if (kLdsTables) price = (long long)s_price[pi];
+        else price = (long long)a.price[pi];
+        v[i] = valid ? price * (long long)qs[i] : 0ll;
+        if (valid) {
+          if (kLdsTables) split_add32(&s_hist[pi], &a.prod_carry[pi], qs[i]);
+          else atomicAdd(&a.prod_carry[pi], (unsigned long long)(long long)qs[i]);
+        }
+      }
+
+      // order boundaries inside the lane's four lines
+      int prev = __shfl_up(ids[3], 1);
+      if (lane == 0) prev = carry_id;
+      const bool h0 = ids[0] != prev, h1 = ids[1] != ids[0], h2 = ids[2] != ids[1], h3 = ids[3] != ids[2];
+      const bool has_head = h0 | h1 | h2 | h3;
+      const long long tot = v[0] + v[1] + v[2] + v[3];
+      // pre: lines before the lane's first boundary (they continue the incoming order)
+      long long pre = 0;
+      {
+        bool open = true;
+        open &= !h0; pre += open ? v[0] : 0;
+        open &= !h1; pre += open ? v[1] : 0;
+        open &= !h2; pre += open ? v[2] : 0;
+        open &= !h3; pre += open ? v[3] : 0;
+      }
+      // tail: lines from the lane's last boundary on
+      long long tail = v[3];
+      {
+        bool open = !h3;
+        tail += open ? v[2] : 0; open &= !h2;
+        tail += open ? v[1] : 0; open &= !h1;
+        tail += open ? v[0] : 0;
+      }
+
+      // incoming[l] = sum of the open order's lines that precede lane l (incl. the carry)
+      const long long incl = wave_inclusive_scan(tot, lane);
+      const long long excl = incl - tot;
+      const unsigned long long headmask = __ballot(has_head);
+      const unsigned long long below = headmask & ((1ull << lane) - 1ull);
+      const int j = below ? (63 - __clzll((long long)below)) : 0;
+      const long long gj = __shfl(tail - incl, j);              // tail[j] - incl[j]
+      const long long incoming = excl + (below ? gj : carry_sum);
+
+      if (first_open && headmask != 0ull) {                       // wave-uniform, once per run
+        const int L = __ffsll((long long)headmask) - 1;
+        head_sum = __shfl(incoming + pre, L);
+        first_open = false;
+      }
+
+      // close orders at every boundary: the lane that sees order b start writes order a's total
+      long long run = incoming;
+      bool gap = false;
+      int pid = prev;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool h = ids[i] != pid;
+        if (h) {
+          const uint32_t idx = (uint32_t)pid - (uint32_t)a.base;
+          if (idx < (uint32_t)a.n_orders) a.order_total[idx] = run; else st |= kStOrderRange;
+          if (ids[i] < pid) st |= kStUnsorted;
+          else if ((uint32_t)ids[i] - (uint32_t)pid > 1u) gap = true;
+          run = 0;
+        }
+        run += v[i];
+        pid = ids[i];
+      }
+      unsigned long long gm = __ballot(gap);
+      while (gm) {                                               // orders with no lines: rare
+        const int L = __ffsll((long long)gm) - 1;
+        gm &= gm - 1ull;
+        const int p0 = __shfl(prev, L), b0 = __shfl(ids[0], L), b1 = __shfl(ids[1], L),
+                  b2 = __shfl(ids[2], L), b3 = __shfl(ids[3], L);
+        wave_fill_gap(a, p0, b0, lane);
+        wave_fill_gap(a, b0, b1, lane);
+        wave_fill_gap(a, b1, b2, lane);
+        wave_fill_gap(a, b2, b3, lane);
+      }
+
+      carry_id = __shfl(ids[3], kWave - 1);
+      carry_sum = __shfl(run, kWave - 1);
+      cid = nid; cpr = npr; cq = nq;
+    }
+
+    // the run's first and last order may continue in the neighbouring waves: hand both to k_fixup
+    if (lane == 0) {
+      const uint32_t idx = (uint32_t)carry_id - (uint32_t)a.base;
+      if (idx >= (uint32_t)a.n_orders) st |= kStOrderRange;
+      a.rec_id[2 * g] = head_id;
+      a.rec_id[2 * g + 1] = carry_id;
+      if (first_open) { a.rec_sum[2 * g] = carry_sum; a.rec_sum[2 * g + 1] = 0; }
+      else            { a.rec_sum[2 * g] = head_sum;  a.rec_sum[2 * g + 1] = carry_sum; }
+    }
+    if (st) atomicOr(a.status, st);
+  }
+
+  if (kLdsTables) {
+    __syncthreads();
+    uint32_t* slab = a.prod_slab + (size_t)blockIdx.x * a.p_pad;
+    for (int i = (int)threadIdx.x; i < P; i += (int)blockDim.x) slab[i] = s_hist[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fixup
+// ---------------------------------------------------------------------------------------------
+struct FixArgs {
+  const int32_t* rec_id;
+  const int64_t* rec_sum;
+  int32_t n_rec;            // 2 * (waves that had work), <= kFixThreads * kFixStrip
+  int32_t base;
+  int32_t n_orders;
+  int64_t* order_total;
+  uint32_t* status;
+  const uint32_t* prod_slab;
+  int32_t n_slabs;
+  int32_t p_pad;
+  int32_t n_products;
+  int32_t merge_products;   // 1: blocks >= 1 merge the stock-delta slabs
+  unsigned long long* prod_carry;
+  int64_t* product_qty;
+};
+
+__device__ __forceinline__ void block_fill_zero(int64_t* out, long long lo, long long hi, int n_orders) {
+  if (lo < 0) lo = 0;
+  if (hi > n_orders) hi = n_orders;
+  for (long long k = lo + threadIdx.x; k < hi; k += blockDim.x) out[k] = 0;
+}
+
+__global__ void __launch_bounds__(kFixThreads) k_fixup(FixArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  if (blockIdx.x > 0) {
+    // ---- stock-delta merge: 64 products per block, wave w sums slabs w, w+16, ...
+    if (!a.merge_products) return;
+    unsigned long long* s_part = reinterpret_cast<unsigned long long*>(smem);   // [16][64]
+    const int p = ((int)blockIdx.x - 1) * kMergeProducts + lane;
+    unsigned long long acc = 0;
+    if (p < a.n_products)
+      for (int s = wave; s < a.n_slabs; s += kFixThreads / 64) acc += a.prod_slab[(size_t)s * a.p_pad + p];
+    s_part[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0 && p < a.n_products) {
+      unsigned long long sum = a.prod_carry[p];
+#pragma unroll
+      for (int w = 0; w < kFixThreads / 64; ++w) sum += s_part[w * 64 + lane];
+      a.product_qty[p] = (int64_t)sum;
+      a.prod_carry[p] = 0ull;           // leave the workspace clean for the next call
+    }
+    return;
+  }
+
+  // ---- block 0: orders cut by wave boundaries.  Records are (order id, partial sum), two per
+  // wave, in line order, hence sorted by id.  Every maximal run of equal ids is one order.
+  long long* s_excl = reinterpret_cast<long long*>(smem);                       // [n_rec]
+  int* s_head = reinterpret_cast<int*>(smem + (size_t)kFixThreads * kFixStrip * 8);   // [n_rec]
+  __shared__ long long s_wsum[kFixThreads / 64];
+  __shared__ int s_wmax[kFixThreads / 64];
+  __shared__ int s_gap_n;
+  __shared__ int s_gap_lo[256], s_gap_hi[256];
+
+  const int n = a.n_rec;
+  const int i0 = tid * kFixStrip;
+  int ids[kFixStrip];
+  long long sums[kFixStrip];
+  int prev_id = 0;
+  uint32_t st = 0;
+  if (tid == 0) s_gap_n = 0;
+#pragma unroll
+  for (int k = 0; k < kFixStrip; ++k) {
+    const int i = i0 + k;
+    ids[k] = i < n ? a.rec_id[i] : 0;
+    sums[k] = i < n ? a.rec_sum[i] : 0;
+  }
+  if (i0 > 0 && i0 < n) prev_id = a.rec_id[i0 - 1];
+
+  long long tsum = 0;
+  int tmax = -1;
+#pragma unroll
+  for (int k = 0; k < kFixStrip; ++k) {
+    const int i = i0 + k;
+    if (i < n) {
+      const bool head = (i == 0) || (ids[k] != (k == 0 ? prev_id : ids[k - 1]));
+      if (head) tmax = i;
+      tsum += sums[k];
+    }
+  }
+  // block scans: exclusive sum of tsum, exclusive running max of tmax
+  long long incl = wave_inclusive_scan(tsum, lane);
+  int mx = tmax;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(mx, d); if (lane >= d) mx = max(mx, t); }
+  if (lane == 63) { s_wsum[wave] = incl; s_wmax[wave] = mx; }
+  __syncthreads();
+  long long woff = 0;
+  int wmx = -1;
+  for (int w = 0; w < wave; ++w) { woff += s_wsum[w]; wmx = max(wmx, s_wmax[w]); }
+  long long run = woff + incl - tsum;                       // exclusive prefix at record i0
+  int mxe = __shfl_up(mx, 1);
+  int cur_head = max(wmx, lane == 0 ? -1 : mxe);            // last head before record i0
+#pragma unroll
+  for (int k = 0; k < kFixStrip; ++k) {
+    const int i = i0 + k;
+    if (i < n) {
+      const bool head = (i == 0) || (ids[k] != (k == 0 ? prev_id : ids[k - 1]));
+      if (head) cur_head = i;
+      s_excl[i] = run;
+      s_head[i] = cur_head;
+      run += sums[k];
+    }
+  }
+  __syncthreads();
+
+  // every run's last record writes the order's total and zero-fills the ids up to the next run
+#pragma unroll
+  for (int k = 0; k < kFixStrip; ++k) {
+    const int i = i0 + k;
+    if (i < n) {
+      const int next_id = (i + 1 < n) ? ((k + 1 < kFixStrip) ? ids[(k + 1) % kFixStrip] : a.rec_id[i + 1]) : 0;
+      const bool tail = (i + 1 == n) || (next_id != ids[k]);
+      if (tail) {
+        const long long total = s_excl[i] + sums[k] - s_excl[s_head[i]];
+        const uint32_t idx = (uint32_t)ids[k] - (uint32_t)a.base;
+        if (idx < (uint32_t)a.n_orders) a.order_total[idx] = total; else st |= kStOrderRange;
+        // Only the step from a wave's tail record (odd i) to the next wave's head record can hide
+        // orders without lines; between a wave's own head and tail k_lines wrote everything.
+        if (i + 1 < n && (i & 1)) {
+          if (next_id < ids[k]) st |= kStUnsorted;
+          else if ((uint32_t)next_id - (uint32_t)ids[k] > 1u) {
+            const int slot = atomicAdd(&s_gap_n, 1);
+            if (slot < 256) { s_gap_lo[slot] = ids[k]; s_gap_hi[slot] = next_id; }
+            else {
+              for (long long q = (long long)ids[k] + 1; q < (long long)next_id; ++q) {
+                const uint32_t qi = (uint32_t)((int)q) - (uint32_t)a.base;
+                if (qi < (uint32_t)a.n_orders) a.order_total[qi] = 0;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int n_gaps = min(s_gap_n, 256);
+  for (int gidx = 0; gidx < n_gaps; ++gidx)
+    block_fill_zero(a.order_total, (long long)s_gap_lo[gidx] + 1 - a.base, (long long)s_gap_hi[gidx] - a.base,
+                    a.n_orders);
+  // orders before the first and after the last line
+  if (n > 0) {
+    block_fill_zero(a.order_total, 0, (long long)a.rec_id[0] - a.base, a.n_orders);
+    block_fill_zero(a.order_total, (long long)a.rec_id[n - 1] + 1 - a.base, a.n_orders, a.n_orders);
+  }
+  if (st) atomicOr(a.status, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_customers / k_custmerge
+// ---------------------------------------------------------------------------------------------
+struct CustArgs {
+  const int32_t* order_customer;   // [M]
+  const int64_t* order_total;      // [M]
+  int64_t n_orders;
+  int64_t n_tiles;                 // ceil(M / 256)
+  int64_t tiles_per_stream;
+  int32_t n_customers;
+  int32_t c_pad;                   // slab row pitch
+  int32_t span;                    // customers per range
+  int32_t n_ranges;                // R
+  int32_t n_streams;
+  uint32_t* cust_slab;             // [n_streams][c_pad]
+  unsigned long long* cust_carry;  // [C] high-word corrections (LDS mode) / the totals (global mode)
+  uint32_t* status;
+};
+
+// Workgroup b: XCD label x = b % 8 (workgroups with equal label share an L2), slot j = b / 8,
+// range r = j % R, stream s = x + 8 * (j / R).  The R siblings of a stream read the same orders.
+template <bool kLdsTables>
+__global__ void __launch_bounds__(1024) k_customers(CustArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* s_tab = reinterpret_cast<uint32_t*>(smem);
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const int waves_per_block = (int)(blockDim.x >> 6);
+  const int x = (int)(blockIdx.x & 7), jslot = (int)(blockIdx.x >> 3);
+  const int r = jslot % a.n_ranges;
+  const int s = x + 8 * (jslot / a.n_ranges);
+  const int lo = r * a.span;
+  int len = a.n_customers - lo;
+  if (len > a.span) len = a.span;
+  if (len < 0) len = 0;
+
+  if (kLdsTables) {
+    for (int i = (int)threadIdx.x; i < len; i += (int)blockDim.x) s_tab[i] = 0u;
+    __syncthreads();
+  }
+  uint32_t st = 0;
+  const long long t0 = (long long)s * a.tiles_per_stream;
+  long long t1 = t0 + a.tiles_per_stream;
+  if (t1 > a.n_tiles) t1 = a.n_tiles;
+  const long long n_full = a.n_orders / kTile;
+  for (long long t = t0 + wave; t < t1; t += waves_per_block) {
+    const long long o0 = t * kTile + (long long)lane * 4;
+    int cs[4];
+    long long tv[4];
+    if (t < n_full) {
+      const int4 c4 = *reinterpret_cast<const int4*>(a.order_customer + o0);
+      const longlong2 ta = *reinterpret_cast<const longlong2*>(a.order_total + o0);
+      const longlong2 tb = *reinterpret_cast<const longlong2*>(a.order_total + o0 + 2);
+      cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w;
+      tv[0] = ta.x; tv[1] = ta.y; tv[2] = tb.x; tv[3] = tb.y;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool in = o0 + i < a.n_orders;
+        cs[i] = in ? a.order_customer[o0 + i] : 0;      // customer 0 with a zero total: adds nothing
+        tv[i] = in ? a.order_total[o0 + i] : 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if ((uint32_t)cs[i] >= (uint32_t)a.n_customers) { st |= kStCustomerRange; continue; }
+      if (kLdsTables) {
+        const uint32_t off = (uint32_t)(cs[i] - lo);
+        if (off < (uint32_t)len && tv[i] != 0) split_add64(&s_tab[off], &a.cust_carry[cs[i]], tv[i]);
+      } else {
+        if (tv[i] != 0) atomicAdd(&a.cust_carry[cs[i]], (unsigned long long)tv[i]);
+      }
+    }
+  }
+  if (st && r == 0) atomicOr(a.status, st);
+  if (kLdsTables) {
+    __syncthreads();
+    uint32_t* slab = a.cust_slab + (size_t)s * a.c_pad + lo;
+    for (int i = (int)threadIdx.x; i < len; i += (int)blockDim.x) slab[i] = s_tab[i];
+  }
+}
+
+struct CustMergeArgs {
+  const uint32_t* cust_slab;
+  int32_t n_streams;
+  int32_t c_pad;
+  int32_t n_customers;
+  unsigned long long* cust_carry;
+  int64_t* customer_total;
+};
+
+__global__ void __launch_bounds__(256) k_custmerge(CustMergeArgs a) {
+  const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (c >= a.n_customers) return;
+  unsigned long long sum = a.cust_carry[c];
+  for (int s = 0; s < a.n_streams; ++s) sum += a.cust_slab[(size_t)s * a.c_pad + c];
+  a.customer_total[c] = (int64_t)sum;
+  a.cust_carry[c] = 0ull;
+}
+
+// Global-table mode epilogue: move the 64-bit accumulators into the output and clear them.
+__global__ void __launch_bounds__(256) k_move_clear(unsigned long long* acc, int64_t* out, int n) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < n) { out[i] = (int64_t)acc[i]; acc[i] = 0ull; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic data
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned long long kGolden = 0x9E3779B97F4A7C15ull;
+constexpr unsigned long long kSeedLen = 0xA11CEull, kSeedProd = 0xB0Bull, kSeedQty = 0x51DEull,
+                             kSeedPrice = 0xCAFEull, kSeedCust = 0xD00Dull;
+constexpr int kSynthOrdersPerBlock = 1024;
+
+__host__ __device__ __forceinline__ unsigned long long synth_hash(unsigned long long seed, unsigned long long i) {
+  unsigned long long z = (seed ^ (i * kGolden)) + kGolden;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+struct SynthArgs {
+  int64_t n_lines_total;
+  int64_t order_lo, order_hi;
+  int64_t line_lo;
+  const int64_t* block_line_off;   // global line index of the first order of every 1024-order block
+  const unsigned long long* cdf;   // Zipf cumulative weights or nullptr
+  unsigned long long wtot;
+  int32_t n_products, n_customers, base, qty_mode;
+  int32_t* order_id;
+  int32_t* product_idx;
+  int32_t* qty;
+  int32_t* order_customer;
+};
+
+__global__ void __launch_bounds__(kSynthOrdersPerBlock) k_synth(SynthArgs a) {
+  __shared__ int s_w[kSynthOrdersPerBlock / 64];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long o = a.order_lo + (long long)blockIdx.x * kSynthOrdersPerBlock + tid;
+  const bool in = o < a.order_hi;
+  const int len = in ? 1 + (int)(synth_hash(kSeedLen, (unsigned long long)o) % 7ull) : 0;
+  int incl = len;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += s_w[w];
+  if (!in) return;
+  const long long start = a.block_line_off[blockIdx.x] + woff + incl - len;
+  a.order_customer[o - a.order_lo] = (int32_t)(synth_hash(kSeedCust, (unsigned long long)o) % (unsigned long long)a.n_customers);
+  for (int i = 0; i < len; ++i) {
+    const long long l = start + i;
+    if (l >= a.n_lines_total) break;                 // the last order is truncated
+    const unsigned long long hp = synth_hash(kSeedProd, (unsigned long long)l);
+    int p;
+    if (a.cdf == nullptr) {
+      p = (int)(hp % (unsigned long long)a.n_products);
+    } else {
+      const unsigned long long u = hp % a.wtot;
+      int lo = 0, hi = a.n_products;                 // first k with cdf[k] > u
+      while (lo < hi) { const int m = lo + (hi - lo) / 2; if (a.cdf[m] > u) hi = m; else lo = m + 1; }
+      p = lo;
+    }
+    const long long k = l - a.line_lo;
+    a.order_id[k] = (int32_t)(a.base + o);
+    a.product_idx[k] = p;
+    a.qty[k] = a.qty_mode ? 1 + (int)(synth_hash(kSeedQty, (unsigned long long)l) % 5ull) : 1;
+  }
+}
+
+}  // namespace acmpc

@@ -1,0 +1,213 @@
+/*
+ * acmpc.h — C ABI of the MI355X (gfx950) checkout-aggregation engine.
+ *
+ * The engine recomputes, in bulk and over columnar arrays, what the reference
+ * storefront's checkout produces one row at a time:
+ *
+ *   order_total_cents[o]    = sum over the `detalle` rows of order o of
+ *                             price_cents[product_idx] * qty
+ *                             (process/carrito.php:12-21 accumulates Precio per
+ *                             cart line; process/confirmcompra.php:24 stores the
+ *                             sum as venta.TotalPagar)
+ *   product_qty[p]          = sum of detalle.CantidadProductos over rows whose
+ *                             CodigoProd is product p (store.sql:97-101,116 —
+ *                             the stock decrement the schema implies)
+ *   customer_total_cents[c] = sum of venta.TotalPagar over the orders whose
+ *                             venta.NIT is customer c (store.sql:158-165,215)
+ *
+ * All arithmetic is two's-complement int64 in cents (wrap-around on overflow,
+ * like unsigned 64-bit addition), so every result is independent of the order
+ * in which partial sums are merged.
+ *
+ * Every entry point is plain C: pointers, sizes, integer return codes.  There
+ * is no CPU backend: a context can only be created on a HIP device, and every
+ * call fails with a negative code (never abort()/exit()) when something is
+ * wrong.  The reference's convention is die("<message>") at
+ * library/consulSQL.php:12,19,31,38,45; a caller that wants that behaviour
+ * maps a non-zero return to die(acmpc_last_error(ctx)).
+ *
+ * Threading: one context is used by one thread at a time.  Many processes may
+ * each hold their own context on the same GPU.
+ */
+#ifndef ACMPC_H
+#define ACMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct acmpc_ctx acmpc_ctx;
+
+/* Return codes. */
+#define ACMPC_OK            0
+#define ACMPC_E_INVALID    -1  /* bad argument (null pointer, negative size, ...)      */
+#define ACMPC_E_HIP        -2  /* a HIP runtime call failed; see acmpc_last_error      */
+#define ACMPC_E_ALIGN      -3  /* a device column is not 16-byte aligned               */
+#define ACMPC_E_DATA       -4  /* input breaks the data contract; see acmpc_status     */
+#define ACMPC_E_STATE      -5  /* call order wrong (e.g. aggregate before products)    */
+#define ACMPC_E_NOMEM      -6  /* host or device allocation failed                     */
+
+/* Bits reported by acmpc_status(): which part of the data contract was broken. */
+#define ACMPC_ST_ORDER_RANGE     1u /* some order_id outside [base, base+M)             */
+#define ACMPC_ST_ORDER_UNSORTED  2u /* order_id column is not non-decreasing            */
+#define ACMPC_ST_CUSTOMER_RANGE  4u /* some order_customer outside [0, C)               */
+
+/* Kernel slots of acmpc_last_kernel_ms(). */
+#define ACMPC_K_LINES      0   /* order-line pass: totals, stock deltas               */
+#define ACMPC_K_FIXUP      1   /* orders cut by a wave boundary + stock-delta merge    */
+#define ACMPC_K_CUSTOMERS  2   /* per-customer pass                                    */
+#define ACMPC_K_CUSTMERGE  3   /* customer partial merge                               */
+#define ACMPC_N_KERNELS    4
+
+/*
+ * Create / destroy a context bound to HIP device `device` (>= 0).
+ * Replaces: ejecutarSQL::conectar(), library/consulSQL.php:5-16 (one connection
+ * per statement there; one long-lived context per worker process here).
+ * acmpc_last_error(NULL) returns the message of a failed acmpc_init.
+ */
+int  acmpc_init(acmpc_ctx** out, int device);
+void acmpc_destroy(acmpc_ctx* ctx);
+
+/* Static or context-owned message of the last failure; never NULL. */
+const char* acmpc_last_error(const acmpc_ctx* ctx);
+
+/* "acmpc <major>.<minor> gfx950". */
+const char* acmpc_version(void);
+
+/*
+ * Load the product table: price_cents[p] is producto.Precio (DECIMAL(30,2),
+ * store.sql:113) of dictionary entry p, in integer cents.  Host pointer.
+ * Replaces the per-line "select * from producto where CodigoProd=..." lookup of
+ * process/carrito.php:13.
+ */
+int acmpc_set_products(acmpc_ctx* ctx, const int64_t* price_cents, int32_t n_products);
+
+/*
+ * Aggregate N order lines (the `detalle` table, store.sql:97-101, one row per
+ * cart entry as written by process/confirmcompra.php:35-37) held in HOST memory.
+ *
+ *   order_id[N]       detalle.NumPedido; non-decreasing (rows of one order are
+ *                     contiguous), each in [order_id_base, order_id_base + M)
+ *   product_idx[N]    dictionary index of detalle.CodigoProd into the product
+ *                     table; any value outside [0, n_products) is an unknown
+ *                     code: it adds nothing to any sum, as an unmatched
+ *                     CodigoProd yields no row at process/carrito.php:13-14
+ *   qty[N]            detalle.CantidadProductos (always 1 in the reference,
+ *                     process/confirmcompra.php:36)
+ *   order_customer[M] venta.NIT (= cliente.id_Cliente) of order
+ *                     order_id_base + i, as a dictionary index in [0, C)
+ *   out_order_total_cents[M], out_product_qty[n_products],
+ *   out_customer_total_cents[C]   results, fully overwritten
+ *
+ * Copies in, runs the device path, copies out, and returns ACMPC_E_DATA if the
+ * data contract was broken (results are then unspecified but no memory outside
+ * the output arrays is touched).
+ * Replaces: the loops of process/carrito.php:12-18 and
+ * process/confirmcompra.php:24,35-37 over one cart, for all carts at once.
+ */
+int acmpc_aggregate(acmpc_ctx* ctx,
+                    const int32_t* order_id, const int32_t* product_idx, const int32_t* qty,
+                    int64_t n_lines,
+                    const int32_t* order_customer, int64_t n_orders,
+                    int32_t order_id_base, int32_t n_customers,
+                    int64_t* out_order_total_cents,
+                    int64_t* out_product_qty,
+                    int64_t* out_customer_total_cents);
+
+/*
+ * Same computation on DEVICE-resident columns and outputs (16-byte aligned
+ * device pointers on the context's device).  Work is enqueued on `hip_stream`
+ * (a hipStream_t; NULL = the default stream) and the call returns without
+ * waiting.  Uses a workspace owned by the context: calls on one context must
+ * not overlap in time.  Contract violations are reported by acmpc_status().
+ */
+int acmpc_aggregate_device(acmpc_ctx* ctx,
+                           const int32_t* d_order_id, const int32_t* d_product_idx,
+                           const int32_t* d_qty, int64_t n_lines,
+                           const int32_t* d_order_customer, int64_t n_orders,
+                           int32_t order_id_base, int32_t n_customers,
+                           int64_t* d_out_order_total_cents,
+                           int64_t* d_out_product_qty,
+                           int64_t* d_out_customer_total_cents,
+                           void* hip_stream);
+
+/*
+ * Wait for `hip_stream`, then store in *flags the OR of ACMPC_ST_* bits raised
+ * by device calls since the previous acmpc_status(), and clear them.
+ * Returns ACMPC_OK when *flags == 0, ACMPC_E_DATA otherwise.
+ */
+int acmpc_status(acmpc_ctx* ctx, void* hip_stream, uint32_t* flags);
+
+/*
+ * Kernel timing.  With profiling enabled every acmpc_aggregate_device() call
+ * brackets each of its kernels with HIP events on the call's stream;
+ * acmpc_last_kernel_ms() waits for them and returns the milliseconds of the
+ * last call's kernels in ms[ACMPC_N_KERNELS].
+ */
+int acmpc_set_profiling(acmpc_ctx* ctx, int enabled);
+int acmpc_last_kernel_ms(acmpc_ctx* ctx, float* ms);
+
+/* Launch geometry of the order-line pass: workgroups and waves per workgroup. */
+int acmpc_lines_geometry(acmpc_ctx* ctx, int32_t* n_workgroups, int32_t* waves_per_workgroup);
+
+/* ------------------------------------------------------------------------
+ * Synthetic store.sql-schema data, integer-only and reproducible bit for bit
+ * on host and device.  These have no counterpart in the reference (which ships
+ * three products and one customer, store.sql:89,126-128); they exist so that
+ * benchmarks can build their input directly in HBM.
+ *
+ *   h(seed, i)          = splitmix64 step applied to (seed XOR i*0x9E3779B97F4A7C15)
+ *   lines of order o    = 1 + h(0xA11CE, o) mod 7; orders are laid out in
+ *                         ascending order id; the last order is truncated so
+ *                         that exactly n_lines_total lines exist
+ *   order_id            = order_id_base + o
+ *   product_idx[l]      = h(0xB0B, l) mod P                      (zipf == 0)
+ *                         upper_bound(cdf, h(0xB0B, l) mod W)    (zipf != 0),
+ *                         cdf[k] = sum_{j<=k} floor(2^32/(j+1)), W = cdf[P-1]
+ *   qty[l]              = 1 (qty_mode 0) or 1 + h(0x51DE, l) mod 5 (qty_mode 1)
+ *   price_cents[p]      = 1 + h(0xCAFE, p) mod 500000, p = 0,1,2 overridden by
+ *                         the seed rows 25000, 45000, 150000 (store.sql:126-128)
+ *   order_customer[o]   = h(0xD00D, o) mod C
+ * l and o are GLOBAL indices, so a shard holds exactly the slice of the
+ * single-device data set that it owns.
+ * ---------------------------------------------------------------------- */
+typedef struct acmpc_synth_cfg {
+  int64_t n_lines_total;   /* lines in the whole data set                  */
+  int32_t n_products;      /* P                                            */
+  int32_t n_customers;     /* C                                            */
+  int32_t order_id_base;   /* 5 = venta AUTO_INCREMENT start, store.sql:232 */
+  int32_t zipf;            /* 0 uniform product popularity, 1 Zipf(s=1)    */
+  int32_t qty_mode;        /* 0: always 1; 1: 1..5                          */
+  int32_t rank;            /* shard index in [0, world)                    */
+  int32_t world;           /* number of shards (order-id ranges)           */
+} acmpc_synth_cfg;
+
+typedef struct acmpc_synth_shard {
+  int64_t n_orders_total;  /* M of the whole data set                       */
+  int64_t order_lo;        /* first global order index of this shard        */
+  int64_t order_hi;        /* one past the last                             */
+  int64_t line_lo;         /* first global line index of this shard         */
+  int64_t line_hi;         /* one past the last                             */
+} acmpc_synth_shard;
+
+/* Host only: where shard cfg->rank of cfg->world begins and ends.  Shards are
+ * contiguous order-index ranges [floor(g*M/G), floor((g+1)*M/G)), cut on order
+ * boundaries so that no order straddles two shards. */
+int acmpc_synth_plan(const acmpc_synth_cfg* cfg, acmpc_synth_shard* out);
+
+/* Host only: fill price_cents[cfg->n_products]. */
+int acmpc_synth_prices(const acmpc_synth_cfg* cfg, int64_t* price_cents);
+
+/* Fill DEVICE arrays with this shard's columns: d_order_id, d_product_idx, d_qty
+ * hold (line_hi - line_lo) entries, d_order_customer holds (order_hi - order_lo).
+ * Enqueued on hip_stream; returns after the work is queued. */
+int acmpc_synth_generate_device(acmpc_ctx* ctx, const acmpc_synth_cfg* cfg,
+                                int32_t* d_order_id, int32_t* d_product_idx, int32_t* d_qty,
+                                int32_t* d_order_customer, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACMPC_H */
