@@ -1,0 +1,100 @@
+"""ctypes binding of libacmpc.so (the C ABI declared in include/acmpc.h).
+
+There is no fallback: if the shared library is missing or fails to load, importing the engine
+raises.  Build it with ``python -m ac_mpc_amd.build`` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libacmpc.so")
+
+# Every symbol include/acmpc.h declares; tests check that the library exports all of them.
+EXPORTS = (
+    "acmpc_init", "acmpc_destroy", "acmpc_last_error", "acmpc_version", "acmpc_set_products",
+    "acmpc_aggregate", "acmpc_aggregate_device", "acmpc_status", "acmpc_set_profiling",
+    "acmpc_last_kernel_ms", "acmpc_lines_geometry", "acmpc_synth_plan", "acmpc_synth_prices",
+    "acmpc_synth_generate_device",
+)
+
+OK, E_INVALID, E_HIP, E_ALIGN, E_DATA, E_STATE, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
+ST_ORDER_RANGE, ST_ORDER_UNSORTED, ST_CUSTOMER_RANGE = 1, 2, 4
+K_LINES, K_FIXUP, K_CUSTOMERS, K_CUSTMERGE, N_KERNELS = 0, 1, 2, 3, 4
+
+
+class SynthCfg(C.Structure):
+    _fields_ = [("n_lines_total", C.c_int64), ("n_products", C.c_int32), ("n_customers", C.c_int32),
+                ("order_id_base", C.c_int32), ("zipf", C.c_int32), ("qty_mode", C.c_int32),
+                ("rank", C.c_int32), ("world", C.c_int32)]
+
+
+class SynthShard(C.Structure):
+    _fields_ = [("n_orders_total", C.c_int64), ("order_lo", C.c_int64), ("order_hi", C.c_int64),
+                ("line_lo", C.c_int64), ("line_hi", C.c_int64)]
+
+
+_lib = None
+
+
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.
+
+    The PyTorch wheel bundles its own libamdhip64.so (soname libamdhip64.so.7, the soname libacmpc.so
+    needs).  If libacmpc.so were loaded first it would pull in /opt/rocm's copy, a later `import torch`
+    would load the bundled one as well, and whichever runtime initialises second finds no device.  So
+    when PyTorch is installed, its runtime is mapped first and libacmpc.so binds to it; without PyTorch
+    the system runtime is used.
+    """
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+def load() -> C.CDLL:
+    """Load libacmpc.so once and declare every prototype.  Raises if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -m ac_mpc_amd.build`). There is no CPU fallback.")
+    _preload_torch_hip_runtime()
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32p = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_uint32)
+    lib.acmpc_init.argtypes = [C.POINTER(vp), C.c_int]
+    lib.acmpc_init.restype = C.c_int
+    lib.acmpc_destroy.argtypes = [vp]
+    lib.acmpc_destroy.restype = None
+    lib.acmpc_last_error.argtypes = [vp]
+    lib.acmpc_last_error.restype = C.c_char_p
+    lib.acmpc_version.argtypes = []
+    lib.acmpc_version.restype = C.c_char_p
+    lib.acmpc_set_products.argtypes = [vp, vp, i32]
+    lib.acmpc_set_products.restype = C.c_int
+    lib.acmpc_aggregate.argtypes = [vp, vp, vp, vp, i64, vp, i64, i32, i32, vp, vp, vp]
+    lib.acmpc_aggregate.restype = C.c_int
+    lib.acmpc_aggregate_device.argtypes = [vp, vp, vp, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp]
+    lib.acmpc_aggregate_device.restype = C.c_int
+    lib.acmpc_status.argtypes = [vp, vp, u32p]
+    lib.acmpc_status.restype = C.c_int
+    lib.acmpc_set_profiling.argtypes = [vp, C.c_int]
+    lib.acmpc_set_profiling.restype = C.c_int
+    lib.acmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.acmpc_last_kernel_ms.restype = C.c_int
+    lib.acmpc_lines_geometry.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.acmpc_lines_geometry.restype = C.c_int
+    lib.acmpc_synth_plan.argtypes = [C.POINTER(SynthCfg), C.POINTER(SynthShard)]
+    lib.acmpc_synth_plan.restype = C.c_int
+    lib.acmpc_synth_prices.argtypes = [C.POINTER(SynthCfg), vp]
+    lib.acmpc_synth_prices.restype = C.c_int
+    lib.acmpc_synth_generate_device.argtypes = [vp, C.POINTER(SynthCfg), vp, vp, vp, vp, vp]
+    lib.acmpc_synth_generate_device.restype = C.c_int
+    _lib = lib
+    return lib

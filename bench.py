@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Benchmark of the checkout-aggregation hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the whole hot path (order-line kernel, fix-up, customer kernel, merge, and for
+N > 1 the single all-reduce of the stock-delta and customer vectors) over one batch of synthetic
+store.sql-schema order lines that already sits in HBM.  Every rank owns a contiguous order-id range of
+one global data set of N x lines-per-gpu lines (weak scaling).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0          # MI355X HBM3E vendor peak (8 TB/s)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--lines-per-gpu", type=int, default=100_000_000)
+    ap.add_argument("--products", type=int, default=10_000)
+    ap.add_argument("--customers", type=int, default=100_000)
+    ap.add_argument("--zipf", type=int, default=0, help="1: Zipf(s=1) product popularity")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(ds, seconds: float):
+    """Time the single-threaded C oracle (a port: the reference's PHP+MySQL path cannot run here) on
+    a bounded prefix of the same columns, repeated for about `seconds` of CPU work."""
+    import numpy as np
+    from tests.oracle_binding import Oracle
+    orc = Oracle()
+    n_s = min(ds.n_lines, 25_000_000)
+    oid = ds.order_id[:n_s].cpu().numpy()
+    # cut the sample on an order boundary
+    last = int(oid[-1])
+    if n_s < ds.n_lines:
+        n_s = int(np.searchsorted(oid, last, side="left"))
+        oid = oid[:n_s]
+    m_s = int(oid[-1]) - ds.order_id_base + 1
+    pidx = ds.product_idx[:n_s].cpu().numpy()
+    qty = ds.qty[:n_s].cpu().numpy()
+    cust = ds.order_customer[:m_s].cpu().numpy()
+    orc.aggregate(oid, pidx, qty, cust, ds.order_id_base, ds.n_customers, ds.price_cents)     # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        orc.aggregate(oid, pidx, qty, cust, ds.order_id_base, ds.n_customers, ds.price_cents)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or reps >= 1000:
+            break
+    return {"value": n_s * reps / el, "unit": "order lines/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_s} lines ({m_s} orders) of the same columns, {reps} passes of the "
+                      f"single-threaded C oracle in {el:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from ac_mpc_amd import MotorLote, reparto, sintetico
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    motor = MotorLote(local_rank)
+    n_total = args.lines_per_gpu * world
+    ds = sintetico.generar(motor, n_total, args.products, args.customers, zipf=bool(args.zipf), qty_mode=0,
+                           rank=rank, world=world)
+    dev = ds.order_id.device
+    P, Cn = args.products, args.customers
+    tot = torch.empty(ds.n_orders, dtype=torch.int64, device=dev)
+    merged = torch.empty(P + Cn, dtype=torch.int64, device=dev)      # [product_qty | customer_total_cents]
+    pq, ct = merged[:P], merged[P:]
+
+    def step():
+        motor.agregar_device(ds.order_id, ds.product_idx, ds.qty, ds.order_customer, ds.order_id_base, Cn, tot, pq, ct)
+        if world > 1:
+            reparto.fusionar(merged)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    assert motor.estado() == 0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert motor.estado() == 0
+
+    # sanity on the result of the last step (cheap, outside the timed region): every line counted once
+    total_qty = int(pq.sum().item())
+    assert total_qty == n_total, (total_qty, n_total)
+
+    # roofline of the dominant kernel (the order-line pass), from HIP events recorded by the library on
+    # the stream the kernels run on
+    motor.perfilar(True)
+    k_ms = {"lines": 0.0, "fixup": 0.0, "customers": 0.0, "custmerge": 0.0}
+    reps = max(5, min(args.steps, 50))
+    for _ in range(reps):
+        motor.agregar_device(ds.order_id, ds.product_idx, ds.qty, ds.order_customer, ds.order_id_base, Cn, tot, pq, ct)
+        ms = motor.ultimos_ms()
+        for k in k_ms:
+            k_ms[k] += ms[k] / reps
+    motor.perfilar(False)
+    # algorithmic bytes of one k_lines launch: three int32 columns per line, one int64 total per order,
+    # one int64 price read and one stock-delta partial written per product
+    b_lines = 12 * ds.n_lines + 8 * ds.n_orders + 16 * P
+    achieved = b_lines / (k_ms["lines"] * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            rec = json.load(open(tpath))
+            key = f"lines={ds.n_lines},zipf={args.zipf}"
+            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        wg, wv = motor.geometria_lineas()
+        out = {
+            "metric": "order lines aggregated/sec (store.sql schema)",
+            "value": n_total * args.steps / elapsed,
+            "unit": "order lines/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64",
+            "data": "synthetic",
+            "config": {
+                "workload": ("BASELINE configs[2]: 100M order lines, per-order totals + per-product stock decrement "
+                             "(+ per-customer totals), single GPU" if world == 1 and args.lines_per_gpu == 100_000_000 else
+                             f"{n_total} order lines sharded by order-id range over {world} GPU(s), one all-reduce"),
+                "lines_per_gpu": args.lines_per_gpu, "lines_total": n_total, "orders_total": ds.n_orders_total,
+                "products": P, "customers": Cn, "product_popularity": "zipf(s=1)" if args.zipf else "uniform",
+                "sharding": f"order-id range x{world}" if world > 1 else "none",
+                "orders_per_sec": ds.n_orders_total * args.steps / elapsed,
+                "lines_kernel_geometry": f"{wg} workgroups x {wv} waves",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
+                "kernel": "k_lines", "kernel_ms": k_ms["lines"], "algorithmic_bytes_per_launch": b_lines,
+                "other_kernels_ms": {k: v for k, v in k_ms.items() if k != "lines"},
+                "whole_step_algorithmic_GBs": (12 * ds.n_lines + 12 * ds.n_orders + 16 * P + 8 * Cn)
+                / (elapsed / args.steps) / 1e9,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ds, args.cpu_baseline_seconds)
+        print(json.dumps(out), flush=True)
+
+    motor.cerrar()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

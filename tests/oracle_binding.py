@@ -1,0 +1,71 @@
+"""ctypes binding of oracle/liboracle.so — the CPU checker.  Test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+class Oracle:
+    def __init__(self):
+        if not os.path.exists(ORACLE_LIB):
+            subprocess.run(["make", "-C", ORACLE_DIR, "liboracle.so"], check=True)
+        lib = C.CDLL(ORACLE_LIB)
+        vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+        lib.oracle_aggregate.argtypes = [vp, vp, vp, i64, vp, i64, i32, i32, vp, i32, vp, vp, vp]
+        lib.oracle_aggregate.restype = C.c_int
+        lib.oracle_hash.argtypes = [C.c_uint64, C.c_uint64]
+        lib.oracle_hash.restype = C.c_uint64
+        lib.oracle_synth_n_orders.argtypes = [i64]
+        lib.oracle_synth_n_orders.restype = i64
+        lib.oracle_synth_prices.argtypes = [i32, vp]
+        lib.oracle_synth_prices.restype = None
+        lib.oracle_synth_count_lines.argtypes = [i64, i64, i64, C.POINTER(i64)]
+        lib.oracle_synth_count_lines.restype = i64
+        lib.oracle_synth_fill.argtypes = [i64, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp]
+        lib.oracle_synth_fill.restype = None
+        self.lib = lib
+
+    def aggregate(self, order_id, product_idx, qty, order_customer, order_id_base, n_customers, price_cents):
+        oid = np.ascontiguousarray(order_id, np.int32)
+        pidx = np.ascontiguousarray(product_idx, np.int32)
+        q = np.ascontiguousarray(qty, np.int32)
+        cust = np.ascontiguousarray(order_customer, np.int32)
+        price = np.ascontiguousarray(price_cents, np.int64)
+        tot = np.empty(cust.size, np.int64)
+        pq = np.empty(price.size, np.int64)
+        ct = np.empty(int(n_customers), np.int64)
+        flags = self.lib.oracle_aggregate(oid.ctypes.data, pidx.ctypes.data, q.ctypes.data, oid.size,
+                                          cust.ctypes.data, cust.size, int(order_id_base), int(n_customers),
+                                          price.ctypes.data, price.size, tot.ctypes.data, pq.ctypes.data,
+                                          ct.ctypes.data)
+        return tot, pq, ct, flags
+
+    def synth_prices(self, n_products):
+        out = np.empty(n_products, np.int64)
+        self.lib.oracle_synth_prices(n_products, out.ctypes.data)
+        return out
+
+    def synth(self, n_lines_total, n_products, n_customers, zipf=0, qty_mode=0, order_lo=0, order_hi=None,
+              order_id_base=5):
+        m_total = int(self.lib.oracle_synth_n_orders(n_lines_total))
+        if order_hi is None:
+            order_hi = m_total
+        line_lo = C.c_int64(0)
+        n = int(self.lib.oracle_synth_count_lines(n_lines_total, order_lo, order_hi, C.byref(line_lo)))
+        m = order_hi - order_lo
+        oid = np.empty(n, np.int32)
+        pidx = np.empty(n, np.int32)
+        qty = np.empty(n, np.int32)
+        cust = np.empty(m, np.int32)
+        self.lib.oracle_synth_fill(n_lines_total, n_products, n_customers, order_id_base, zipf, qty_mode,
+                                   order_lo, order_hi, oid.ctypes.data, pidx.ctypes.data, qty.ctypes.data,
+                                   cust.ctypes.data)
+        return dict(order_id=oid, product_idx=pidx, qty=qty, order_customer=cust, n_orders_total=m_total,
+                    line_lo=int(line_lo.value), order_id_base=order_id_base + order_lo)

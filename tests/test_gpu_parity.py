@@ -1,0 +1,276 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle.  Bar: bit-exact, every output.
+
+Run on the GPU box: python -u -m pytest tests -m gpu -x -v --timeout 120 --timeout-method thread
+"""
+import ctypes as C
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ac_mpc_amd import ErrorLote, _lib, consultasLote, sintetico
+from oracle import checkout_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+VECTORS = sorted(glob.glob(os.path.join(GOLDEN, "synth_*.npz")))
+
+
+def _check(motor, oracle, oid, pidx, qty, cust, base, c_n, price):
+    motor.cargar_productos(price)
+    tot, pq, ct = motor.agregar(oid, pidx, qty, cust, base, c_n)
+    etot, epq, ect, flags = oracle.aggregate(oid, pidx, qty, cust, base, c_n, price)
+    assert flags == 0
+    np.testing.assert_array_equal(tot, etot)
+    np.testing.assert_array_equal(pq, epq)
+    np.testing.assert_array_equal(ct, ect)
+    return tot, pq, ct
+
+
+# ---- committed golden vectors --------------------------------------------------------------
+
+@pytest.mark.parametrize("path", VECTORS, ids=lambda p: os.path.basename(p)[:-4])
+def test_golden_vectors(motor, path):
+    v = np.load(path)
+    motor.cargar_productos(v["price_cents"])
+    tot, pq, ct = motor.agregar(v["order_id"], v["product_idx"], v["qty"], v["order_customer"],
+                                int(v["order_id_base"]), int(v["n_customers"]))
+    np.testing.assert_array_equal(tot, v["order_total_cents"])
+    np.testing.assert_array_equal(pq, v["product_qty"])
+    np.testing.assert_array_equal(ct, v["customer_total_cents"])
+
+
+def test_checkout_cases_through_the_engine(motor):
+    """The hand-derived carts of the reference's seed data: venta.TotalPagar recomputed from detalle."""
+    seed = json.load(open(os.path.join(GOLDEN, "store_seed.json")))
+    store = co.Store.from_seed(seed)
+    chk = co.Checkout(store)
+    for cart in (["1", "2", "3"], ["1", "1"], ["3"], ["2", "2", "2", "1"]):
+        ses = co.Session()
+        for code in cart:
+            chk.carrito(ses, code)
+        chk.confirmcompra(ses, "wilow", co.md5("123"))
+    codes = [r["CodigoProd"] for r in seed["producto"]]
+    cents = [co.to_cents(store.producto[c]) for c in codes]
+    consultasLote._motor = motor
+    consultasLote.CargarProductos(codes, cents)
+    det = store.detalle
+    res = consultasLote.AgregarDetalle([r[0] for r in det], [r[1] for r in det], [r[2] for r in det],
+                                       [0] * len(store.venta), 5, 1)
+    consultasLote._motor = None
+    assert res["TotalPagar"].tolist() == [co.to_cents(v["TotalPagar"]) for v in store.venta] == [220000, 50000, 150000, 160000]
+    assert res["DeltaStock"].tolist() == [4, 4, 2]
+    assert res["TotalCliente"].tolist() == [580000]
+
+
+def test_unknown_code_adds_nothing(motor):
+    consultasLote._motor = motor
+    consultasLote.CargarProductos(["1", "2", "3"], [25000, 45000, 150000])
+    res = consultasLote.AgregarDetalle([5, 5], ["3", "999"], [1, 1], [0], 5, 1)
+    consultasLote._motor = None
+    assert res["TotalPagar"].tolist() == [150000]          # process/carrito.php:13-14: no row, no add
+    assert res["DeltaStock"].tolist() == [0, 0, 1]
+
+
+# ---- seeded sizes against the C oracle --------------------------------------------------------
+
+@pytest.mark.parametrize("n,p,c,zipf,qm", [
+    (1, 3, 1, 0, 0), (255, 10, 7, 0, 1), (256, 10, 7, 1, 1), (257, 10, 7, 0, 0), (4097, 50, 9, 1, 1),
+    (1_000_003, 10_000, 100_000, 0, 1), (1_000_000, 10_000, 100_000, 1, 0), (3_333_333, 12_000, 250_000, 1, 1),
+])
+def test_seeded_sizes(motor, oracle, n, p, c, zipf, qm):
+    d = oracle.synth(n, p, c, zipf=zipf, qty_mode=qm)
+    _check(motor, oracle, d["order_id"], d["product_idx"], d["qty"], d["order_customer"], 5, c, oracle.synth_prices(p))
+
+
+def test_large_product_and_customer_tables_use_global_path(motor, oracle):
+    """P too large for the LDS tables, C too large for the LDS customer ranges."""
+    n, p, c = 500_000, 60_000, 3_000_000
+    d = oracle.synth(n, p, c, zipf=0, qty_mode=1)
+    _check(motor, oracle, d["order_id"], d["product_idx"], d["qty"], d["order_customer"], 5, c, oracle.synth_prices(p))
+
+
+# ---- edge cases of the data contract -----------------------------------------------------------
+
+def test_empty_input(motor, oracle):
+    price = np.array([100, 200, 300], np.int64)
+    e = np.zeros(0, np.int32)
+    _check(motor, oracle, e, e, e, e, 5, 4, price)                                   # no orders, no lines
+    _check(motor, oracle, e, e, e, np.array([1, 2, 3], np.int32), 5, 4, price)       # orders without lines
+
+
+def test_orders_without_lines_are_zero(motor, oracle):
+    rng = np.random.default_rng(3)
+    m = 50_000
+    lens = rng.integers(0, 4, m)
+    lens[rng.integers(0, m, 200)] = 0
+    lens[1000:9000] = 0                                  # a long run of empty orders inside
+    lens[:300] = 0                                       # and at both ends
+    lens[-300:] = 0
+    oid = np.repeat(np.arange(m, dtype=np.int32) + 5, lens)
+    pidx = rng.integers(0, 100, oid.size).astype(np.int32)
+    qty = rng.integers(1, 4, oid.size).astype(np.int32)
+    cust = rng.integers(0, 77, m).astype(np.int32)
+    _check(motor, oracle, oid, pidx, qty, cust, 5, 77, rng.integers(1, 10**6, 100).astype(np.int64))
+
+
+def test_sparse_lines_in_a_huge_order_range(motor, oracle):
+    """Three lines, four million orders: the zero fill of absent orders must be cooperative, not serial."""
+    m = 4_000_000
+    oid = np.array([5 + 10, 5 + 2_000_000, 5 + m - 2], np.int32)
+    pidx = np.array([0, 1, 2], np.int32)
+    qty = np.array([1, 2, 3], np.int32)
+    cust = (np.arange(m) % 13).astype(np.int32)
+    _check(motor, oracle, oid, pidx, qty, cust, 5, 13, np.array([7, 11, 13], np.int64))
+
+
+def test_one_order_spanning_every_wave(motor, oracle):
+    n = 2_000_000
+    oid = np.full(n, 5, np.int32)
+    rng = np.random.default_rng(5)
+    pidx = rng.integers(0, 500, n).astype(np.int32)
+    qty = np.ones(n, np.int32)
+    _check(motor, oracle, oid, pidx, qty, np.array([0], np.int32), 5, 1, rng.integers(1, 10**5, 500).astype(np.int64))
+
+
+def test_ragged_orders_long_and_short(motor, oracle):
+    rng = np.random.default_rng(11)
+    lens = np.concatenate([rng.integers(1, 8, 5000), [300_000], rng.integers(1, 3, 5000), [70_000, 1, 1, 90_000],
+                           rng.integers(1, 2000, 300)])
+    m = lens.size
+    oid = np.repeat(np.arange(m, dtype=np.int32) + 1_000_000, lens)
+    pidx = rng.integers(-1, 10_000, oid.size).astype(np.int32)
+    qty = rng.integers(-2, 9, oid.size).astype(np.int32)
+    cust = rng.integers(0, 100_000, m).astype(np.int32)
+    _check(motor, oracle, oid, pidx, qty, cust, 1_000_000, 100_000, oracle.synth_prices(10_000))
+
+
+def test_int64_prices_and_wraparound(motor, oracle):
+    rng = np.random.default_rng(13)
+    n, p = 300_000, 2000
+    d = oracle.synth(n, p, 500, zipf=1, qty_mode=1)
+    price = rng.integers(-2**62, 2**62, p).astype(np.int64)
+    qty = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+    _check(motor, oracle, d["order_id"], d["product_idx"], qty, d["order_customer"], 5, 500, price)
+
+
+def test_hot_key_quantity_carries(motor, oracle):
+    """One product takes every line with quantities near 2^31: the 32-bit LDS partials must carry."""
+    n = 600_000
+    oid = np.repeat(np.arange(n // 4, dtype=np.int32) + 5, 4)
+    pidx = np.zeros(n, np.int32)
+    qty = np.full(n, 2_000_000_000, np.int32)
+    qty[::3] = -1_999_999_999
+    cust = np.zeros(n // 4, np.int32)
+    _check(motor, oracle, oid, pidx, qty, cust, 5, 3, np.array([3, 5], np.int64))
+
+
+def test_negative_order_ids_and_base(motor, oracle):
+    rng = np.random.default_rng(17)
+    m = 3000
+    lens = rng.integers(1, 6, m)
+    oid = np.repeat(np.arange(m, dtype=np.int32) - 1500, lens)
+    pidx = rng.integers(0, 9, oid.size).astype(np.int32)
+    qty = np.ones(oid.size, np.int32)
+    _check(motor, oracle, oid, pidx, qty, rng.integers(0, 5, m).astype(np.int32), -1500, 5,
+           rng.integers(1, 999, 9).astype(np.int64))
+
+
+def test_contract_violations_are_reported_not_fatal(motor):
+    motor.cargar_productos(np.array([100, 200], np.int64))
+    with pytest.raises(ErrorLote) as e:
+        motor.agregar([5, 6, 9], [0, 1, 0], [1, 1, 1], [0, 0], 5, 1)       # order id outside [5, 7)
+    assert e.value.code == _lib.E_DATA and "order_id outside" in e.value.detail
+    with pytest.raises(ErrorLote) as e:
+        motor.agregar([6, 5], [0, 1], [1, 1], [0, 0], 5, 1)                # unsorted
+    assert e.value.code == _lib.E_DATA and "non-decreasing" in e.value.detail
+    with pytest.raises(ErrorLote) as e:
+        motor.agregar([5, 6], [0, 1], [1, 1], [0, 3], 5, 1)                # customer outside [0, 1)
+    assert e.value.code == _lib.E_DATA and "order_customer" in e.value.detail
+    tot, pq, ct = motor.agregar([5, 6], [0, 1], [1, 1], [0, 0], 5, 1)      # the context still works
+    assert tot.tolist() == [100, 200] and pq.tolist() == [1, 1] and ct.tolist() == [300]
+
+
+def test_aggregate_before_products_is_a_state_error():
+    from ac_mpc_amd import MotorLote
+    m = MotorLote(0)
+    try:
+        with pytest.raises(ErrorLote) as e:
+            m.agregar([5], [0], [1], [0], 5, 1)
+        assert e.value.code == _lib.E_STATE
+    finally:
+        m.cerrar()
+
+
+# ---- device-resident path, generator parity, properties at full size ------------------------------
+
+def _device_run(motor, ds):
+    import torch
+    dev = ds.order_id.device
+    tot = torch.empty(ds.n_orders, dtype=torch.int64, device=dev)
+    pc = torch.empty(motor.n_products + ds.n_customers, dtype=torch.int64, device=dev)
+    pq, ct = pc[:motor.n_products], pc[motor.n_products:]
+    motor.agregar_device(ds.order_id, ds.product_idx, ds.qty, ds.order_customer, ds.order_id_base, ds.n_customers,
+                         tot, pq, ct)
+    assert motor.estado() == 0
+    return tot, pq, ct
+
+
+@pytest.mark.parametrize("zipf,qm", [(0, 0), (1, 1)])
+def test_device_generator_and_device_path(motor, oracle, zipf, qm):
+    n, p, c = 2_000_003, 10_000, 100_000
+    ds = sintetico.generar(motor, n, p, c, zipf=bool(zipf), qty_mode=qm)
+    d = oracle.synth(n, p, c, zipf=zipf, qty_mode=qm)
+    np.testing.assert_array_equal(ds.order_id.cpu().numpy(), d["order_id"])
+    np.testing.assert_array_equal(ds.product_idx.cpu().numpy(), d["product_idx"])
+    np.testing.assert_array_equal(ds.qty.cpu().numpy(), d["qty"])
+    np.testing.assert_array_equal(ds.order_customer.cpu().numpy(), d["order_customer"])
+    tot, pq, ct = _device_run(motor, ds)
+    etot, epq, ect, _ = oracle.aggregate(d["order_id"], d["product_idx"], d["qty"], d["order_customer"], 5, c, ds.price_cents)
+    np.testing.assert_array_equal(tot.cpu().numpy(), etot)
+    np.testing.assert_array_equal(pq.cpu().numpy(), epq)
+    np.testing.assert_array_equal(ct.cpu().numpy(), ect)
+    # a second call on the same context must not see leftovers of the first
+    tot2, pq2, ct2 = _device_run(motor, ds)
+    assert bool((tot2 == tot).all()) and bool((pq2 == pq).all()) and bool((ct2 == ct).all())
+
+
+def test_shards_merge_to_the_single_device_result(motor, oracle):
+    """world=3 shards run one after the other on one GPU; summed vectors equal the unsharded run."""
+    n, p, c = 1_500_000, 10_000, 100_000
+    whole = sintetico.generar(motor, n, p, c, zipf=True, qty_mode=1)
+    tot, pq, ct = _device_run(motor, whole)
+    tot, pq, ct = tot.cpu().numpy(), pq.cpu().numpy(), ct.cpu().numpy()
+    parts, spq, sct = [], np.zeros(p, np.int64), np.zeros(c, np.int64)
+    for g in range(3):
+        sh = sintetico.generar(motor, n, p, c, zipf=True, qty_mode=1, rank=g, world=3)
+        t, a, b = _device_run(motor, sh)
+        parts.append(t.cpu().numpy())
+        spq += a.cpu().numpy()
+        sct += b.cpu().numpy()
+    np.testing.assert_array_equal(np.concatenate(parts), tot)
+    np.testing.assert_array_equal(spq, pq)
+    np.testing.assert_array_equal(sct, ct)
+
+
+@pytest.mark.parametrize("zipf", [0, 1])
+def test_full_size_100m_lines(motor, oracle, zipf):
+    """BASELINE config 3 (and the per-GPU share of configs 4/5): size-independent invariants, then the
+    C oracle itself on the same columns (it needs ~0.2 s for 100M lines)."""
+    import torch
+    n, p, c = 100_000_000, 10_000, 100_000
+    ds = sintetico.generar(motor, n, p, c, zipf=bool(zipf), qty_mode=0)
+    tot, pq, ct = _device_run(motor, ds)
+    price = torch.from_numpy(ds.price_cents).to(tot.device)
+    assert int(pq.sum()) == n                                            # qty == 1 on every line
+    assert int(tot.sum()) == int(ct.sum()) == int((pq * price).sum())    # money is conserved three ways
+    assert int(tot.min()) >= 1 and int(tot.max()) <= 7 * 500_000        # 1..7 lines of at most 5,000.00
+    oid, pidx, qty, cust = (t.cpu().numpy() for t in (ds.order_id, ds.product_idx, ds.qty, ds.order_customer))
+    etot, epq, ect, flags = oracle.aggregate(oid, pidx, qty, cust, 5, c, ds.price_cents)
+    assert flags == 0
+    np.testing.assert_array_equal(tot.cpu().numpy(), etot)
+    np.testing.assert_array_equal(pq.cpu().numpy(), epq)
+    np.testing.assert_array_equal(ct.cpu().numpy(), ect)
