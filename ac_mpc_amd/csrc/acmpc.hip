@@ -125,6 +125,7 @@ struct LinesPlan {
   bool price32;
   size_t lds_bytes;
   int threads, blocks, waves_per_block;
+  uint32_t stage_cap;
   int64_t n_tiles, tiles_per_wave;
   int n_active_waves;
 };
@@ -133,12 +134,19 @@ int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p) {
   const size_t need32 = (size_t)ctx->p_pad * 8, need64 = (size_t)ctx->p_pad * 12;
   p->price32 = ctx->price_fits32;
   p->lds_bytes = p->price32 ? need32 : need64;
-  p->lds_tables = !ctx->force_global_tables && p->lds_bytes + kLdsReserve <= (size_t)kMaxLds;
-  if (!p->lds_tables) { p->lds_bytes = 0; p->price32 = false; }
   p->threads = ctx->k1_threads;
   p->waves_per_block = p->threads / kWave;
+  // besides the tables every wave stages finished order totals: at least 256 slots of 8 bytes
+  const size_t min_stage = (size_t)p->waves_per_block * kTile * 8 + kWave * 8;
+  p->lds_tables = !ctx->force_global_tables && p->lds_bytes + min_stage + kLdsReserve <= (size_t)kMaxLds;
+  if (!p->lds_tables) { p->lds_bytes = 0; p->price32 = false; }
+  p->stage_cap = 512;
+  while (p->stage_cap > kTile &&
+         p->lds_bytes + (size_t)p->waves_per_block * p->stage_cap * 8 + kWave * 8 + kLdsReserve > (size_t)kMaxLds)
+    p->stage_cap >>= 1;
+  p->lds_bytes += (size_t)p->waves_per_block * p->stage_cap * 8 + kWave * 8;
   int bpc = ctx->k1_blocks_per_cu;
-  if (p->lds_tables) {
+  {
     const int fit = (int)((size_t)kMaxLds / (p->lds_bytes + kLdsReserve));
     bpc = std::max(1, std::min(bpc, fit));
   }
@@ -204,7 +212,7 @@ int clear_carries(acmpc_ctx* ctx, hipStream_t st) {
 template <typename PriceT, bool kLds>
 int launch_lines(acmpc_ctx* ctx, const LinesPlan& pl, const LinesArgs& a, hipStream_t st) {
   auto kern = k_lines<PriceT, kLds>;
-  if (pl.lds_bytes > 48 * 1024) {
+  {
     int rc = set_dyn_lds(ctx, kern, pl.lds_bytes);
     if (rc) return rc;
   }
@@ -257,6 +265,13 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.n_lines = n_lines; a.n_tiles = lp.n_tiles; a.tiles_per_wave = lp.tiles_per_wave;
     a.base = base; a.n_orders = (int32_t)n_orders;
     a.price = ctx->d_price.p; a.n_products = P; a.p_pad = ctx->p_pad;
+    {
+      // a workgroup adds at most lines_per_block quantities below q_small into a 32-bit cell
+      const uint64_t lines_per_block = (uint64_t)lp.tiles_per_wave * kTile * lp.waves_per_block;
+      const uint64_t lim = 0xffffffffull / std::max<uint64_t>(1, lines_per_block);
+      a.q_small = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(65536, lim));
+      a.stage_cap = lp.stage_cap;
+    }
     a.order_total = d_tot; a.prod_slab = ctx->d_prod_slab.p; a.prod_carry = ctx->d_prod_carry.p;
     a.rec_id = ctx->d_rec_id.p; a.rec_sum = ctx->d_rec_sum.p; a.status = ctx->d_status;
 

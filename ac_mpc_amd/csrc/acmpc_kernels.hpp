@@ -47,6 +47,8 @@ struct LinesArgs {
   const int64_t* price;     // [P] device
   int32_t n_products;
   int32_t p_pad;            // P rounded up to a multiple of 4
+  uint32_t q_small;         // quantities in [0, q_small) use the 32-bit LDS histogram
+  uint32_t stage_cap;       // staging slots per wave (orders buffered in LDS before they are written)
   int64_t* order_total;     // [M]
   uint32_t* prod_slab;      // [gridDim.x][p_pad] low words of the per-workgroup stock deltas
   unsigned long long* prod_carry;   // [P] high-word corrections (LDS mode) / product_qty itself (global mode)
@@ -57,25 +59,48 @@ struct LinesArgs {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
 
-__device__ __forceinline__ long long wave_inclusive_scan(long long v, int lane) {
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    long long t = __shfl_up(v, d);
-    if (lane >= d) v += t;
-  }
+// 16-byte streaming load: the line columns are read exactly once, so they are loaded with the
+// non-temporal hint and do not displace the output lines and tables that the caches should keep.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 load_stream16(const int32_t* p) {
+  const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(p));
+  return make_int4(v.x, v.y, v.z, v.w);
+}
+
+// One Hillis-Steele step of a 64-bit wave scan through DPP (no LDS traffic, no waits).
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ long long dpp_scan_step(long long v) {
+  const int lo = (int)v, hi = (int)(v >> 32);
+  const int slo = __builtin_amdgcn_update_dpp(0, lo, kCtrl, kRowMask, 0xf, false);
+  const int shi = __builtin_amdgcn_update_dpp(0, hi, kCtrl, kRowMask, 0xf, false);
+  return v + (long long)(((unsigned long long)(unsigned int)shi << 32) | (unsigned int)slo);
+}
+
+// Inclusive prefix sum over the 64 lanes: row_shr 1,2,4,8 inside each 16-lane row, then the row
+// totals are broadcast into the following rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into
+// rows 2 and 3).
+__device__ __forceinline__ long long wave_inclusive_scan(long long v) {
+  v = dpp_scan_step<0x111, 0xf>(v);
+  v = dpp_scan_step<0x112, 0xf>(v);
+  v = dpp_scan_step<0x114, 0xf>(v);
+  v = dpp_scan_step<0x118, 0xf>(v);
+  v = dpp_scan_step<0x142, 0xa>(v);
+  v = dpp_scan_step<0x143, 0xc>(v);
   return v;
 }
 
-// Add a sign-extended 32-bit quantity to a 64-bit accumulator that is split into a 32-bit low
-// word in LDS and a (rare) high-word correction in global memory.  Exact modulo 2^64.
-__device__ __forceinline__ void split_add32(uint32_t* lds_lo, unsigned long long* g_hi, int32_t q) {
-  const uint32_t uq = (uint32_t)q;
-  const uint32_t old = atomicAdd(lds_lo, uq);
-  const int32_t carry = ((uint32_t)(old + uq) < old) ? 1 : 0;
-  const int32_t hi = (q >> 31) + carry;
-  if (hi != 0) atomicAdd(g_hi, ((unsigned long long)(long long)hi) << 32);
+// Value of lane-1 (lane 0 receives `first`).
+__device__ __forceinline__ int wave_shift_up1(int v, int first) {
+  return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);   // wave_shr:1
 }
 
+__device__ __forceinline__ long long readlane64(long long v, int l) {
+  const int lo = __builtin_amdgcn_readlane((int)v, l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+  return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
+}
+
+// Add a 64-bit value to an accumulator that is split into a 32-bit low word in LDS and a (rare)
+// high-word correction in global memory.  Exact modulo 2^64.
 __device__ __forceinline__ void split_add64(uint32_t* lds_lo, unsigned long long* g_hi, long long v) {
   const uint32_t lo = (uint32_t)v;
   const uint32_t old = atomicAdd(lds_lo, lo);
@@ -95,17 +120,185 @@ __device__ __forceinline__ void wave_fill_gap(const LinesArgs& a, int ida, int i
 // ---------------------------------------------------------------------------------------------
 // k_lines
 // ---------------------------------------------------------------------------------------------
+// Per-wave state carried from tile to tile.
+struct WaveRun {
+  int id;               // order id of the last line seen (the order still open)
+  long long sum;        // its partial total so far
+  bool first_open;      // no order boundary seen yet in this wave's run
+  long long head_sum;   // partial total of the run's first order (valid once first_open is false)
+  uint32_t st;          // data-contract flags raised by this lane
+  uint32_t buf_base;    // order index (id - base) that staging slot 0 stands for
+};
+
+// Write the finished part of the wave's staging buffer — order indices [buf_base, buf_base + n) —
+// to order_total as contiguous 8-byte stores, and leave the buffer zeroed.  Slots never written
+// belong to orders without lines and flush as 0.
+__device__ __forceinline__ void stage_flush(const LinesArgs& a, long long* s_stage, WaveRun& o, uint32_t n, int lane) {
+  for (uint32_t k = (uint32_t)lane; k < n; k += kWave) {
+    const long long val = s_stage[k];
+    s_stage[k] = 0;
+    const uint32_t idx = o.buf_base + k;
+    if (idx < (uint32_t)a.n_orders) a.order_total[idx] = val; else o.st |= kStOrderRange;
+  }
+  o.buf_base += n;
+}
+
+// One 256-line tile: lane l holds lines 4l..4l+3 of the tile in (ids, prs, qs).
+template <typename PriceT, bool kLdsTables>
+__device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_price, uint32_t* s_hist,
+                                           long long* s_stage, long long* s_dummy,
+                                           const int (&ids)[4], const int (&prs)[4], const int (&qs)[4],
+                                           int lane, WaveRun& o) {
+  const uint32_t P = (uint32_t)a.n_products;
+  // price gather, line value, stock delta.  Quantities in [0, q_small) go to the 32-bit LDS
+  // histogram with a non-returning add (the host sizes q_small so that a workgroup's sum cannot
+  // wrap); anything else (negative or huge, never produced by the reference) goes to a 64-bit
+  // global atomic.
+  long long v[4];
+  bool valid[4];
+  int pi[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    valid[i] = (uint32_t)prs[i] < P;
+    pi[i] = valid[i] ? prs[i] : 0;
+  }
+  long long price[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (kLdsTables) price[i] = (long long)s_price[pi[i]];
+    else price[i] = (long long)a.price[pi[i]];
+  }
+  uint32_t rare = 0;                 // bit 0: a quantity needs the 64-bit path; bit 1: ids not sorted
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (kLdsTables) {
+      const bool small = (uint32_t)qs[i] < a.q_small;
+      const uint32_t add = (valid[i] && small) ? (uint32_t)qs[i] : 0u;
+      __hip_atomic_fetch_add(&s_hist[pi[i]], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      rare |= (valid[i] && !small) ? 1u : 0u;
+    } else {
+      rare |= valid[i] ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = valid[i] ? price[i] * (long long)qs[i] : 0ll;
+
+  // order boundaries inside the lane's four lines
+  const int prev = wave_shift_up1(ids[3], o.id);
+  const bool h0 = ids[0] != prev, h1 = ids[1] != ids[0], h2 = ids[2] != ids[1], h3 = ids[3] != ids[2];
+  const bool has_head = h0 | h1 | h2 | h3;
+  rare |= (ids[0] < prev || ids[1] < ids[0] || ids[2] < ids[1] || ids[3] < ids[2]) ? 2u : 0u;
+  const long long tot = v[0] + v[1] + v[2] + v[3];
+  // tail: the lane's lines from its last boundary on
+  long long tail = v[3];
+  {
+    bool open = !h3;
+    tail += open ? v[2] : 0; open &= !h2;
+    tail += open ? v[1] : 0; open &= !h1;
+    tail += open ? v[0] : 0;
+  }
+  // incoming[l] = partial total, at the start of lane l, of the order that is open there:
+  // everything since the nearest boundary in a lower lane, or the carry plus everything so far.
+  const long long incl = wave_inclusive_scan(tot);
+  const long long excl = incl - tot;
+  const unsigned long long headmask = __ballot(has_head);
+  const unsigned long long below = headmask & ((1ull << lane) - 1ull);
+  const int j = below ? (63 - __clzll((long long)below)) : 0;
+  const long long gj = __shfl(tail - incl, j);              // tail[j] - incl[j]
+  const long long incoming = excl + (below ? gj : o.sum);
+
+  if (o.first_open && headmask != 0ull) {                     // wave-uniform, once per run
+    // pre: lines of the first boundary lane that still belong to the run's first order
+    long long pre = 0;
+    bool open = true;
+    open &= !h0; pre += open ? v[0] : 0;
+    open &= !h1; pre += open ? v[1] : 0;
+    open &= !h2; pre += open ? v[2] : 0;
+    const int L = __ffsll((long long)headmask) - 1;
+    o.head_sum = readlane64(incoming + pre, L);
+    o.first_open = false;
+  }
+
+  const int new_id = __builtin_amdgcn_readlane(ids[3], kWave - 1);
+  const uint32_t span = ((uint32_t)new_id - (uint32_t)a.base) - o.buf_base;   // slots this tile can touch
+  const unsigned long long rare_mask = __ballot(rare != 0u);
+  long long run = incoming;
+  int pid = prev;
+
+  if (rare_mask == 0ull && span <= a.stage_cap) {
+    // ---- common path: every order that closes in this tile goes to its staging slot; lanes without
+    // a boundary at line i write a scratch slot instead of branching.
+    const uint32_t off = (uint32_t)a.base + o.buf_base;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool h = ids[i] != pid;
+      const uint32_t slot = (uint32_t)pid - off;
+      long long* dst = (h && slot < a.stage_cap) ? (s_stage + slot) : (s_dummy + lane);
+      *dst = run;
+      run = h ? 0ll : run;
+      run += v[i];
+      pid = ids[i];
+    }
+    o.id = new_id;
+    o.sum = readlane64(run, kWave - 1);
+    if (span > a.stage_cap - kTile) stage_flush(a, s_stage, o, span, lane);
+    return;
+  }
+
+  // ---- rare path: 64-bit quantities, unsorted ids, or a jump in order ids wider than the staging
+  // buffer.  Empty the buffer, then write this tile's orders (and the ids they skip) directly.
+  stage_flush(a, s_stage, o, min(((uint32_t)o.id - (uint32_t)a.base) - o.buf_base, a.stage_cap), lane);
+  if (rare & 1u) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (valid[i] && (!kLdsTables || (uint32_t)qs[i] >= a.q_small))
+        atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qs[i]);
+  }
+  if (rare & 2u) o.st |= kStUnsorted;
+  bool gap = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (ids[i] != pid) {
+      const uint32_t idx = (uint32_t)pid - (uint32_t)a.base;
+      if (idx < (uint32_t)a.n_orders) a.order_total[idx] = run; else o.st |= kStOrderRange;
+      if (ids[i] >= pid && (uint32_t)ids[i] - (uint32_t)pid > 1u) gap = true;
+      run = 0;
+    }
+    run += v[i];
+    pid = ids[i];
+  }
+  unsigned long long gm = __ballot(gap);
+  while (gm) {                                                 // orders with no lines
+    const int L = __ffsll((long long)gm) - 1;
+    gm &= gm - 1ull;
+    const int p0 = __builtin_amdgcn_readlane(prev, L), b0 = __builtin_amdgcn_readlane(ids[0], L),
+              b1 = __builtin_amdgcn_readlane(ids[1], L), b2 = __builtin_amdgcn_readlane(ids[2], L),
+              b3 = __builtin_amdgcn_readlane(ids[3], L);
+    wave_fill_gap(a, p0, b0, lane);
+    wave_fill_gap(a, b0, b1, lane);
+    wave_fill_gap(a, b1, b2, lane);
+    wave_fill_gap(a, b2, b3, lane);
+  }
+  o.id = new_id;
+  o.sum = readlane64(run, kWave - 1);
+  o.buf_base = (uint32_t)new_id - (uint32_t)a.base;            // staging restarts at the open order
+}
+
 template <typename PriceT, bool kLdsTables>
 __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  PriceT* s_price = reinterpret_cast<PriceT*>(smem);
-  uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + (size_t)a.p_pad * sizeof(PriceT));
-
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
   const int waves_per_block = (int)(blockDim.x >> 6);
   const int P = a.n_products;
+  // LDS: [price table][stock-delta histogram] (only with kLdsTables) [staging, one slice per wave][scratch]
+  const size_t tables = kLdsTables ? (size_t)a.p_pad * (sizeof(PriceT) + sizeof(uint32_t)) : 0;
+  PriceT* s_price = reinterpret_cast<PriceT*>(smem);
+  uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + (size_t)a.p_pad * sizeof(PriceT));
+  long long* s_stage = reinterpret_cast<long long*>(smem + tables) + (size_t)wave * a.stage_cap;
+  long long* s_dummy = reinterpret_cast<long long*>(smem + tables) + (size_t)waves_per_block * a.stage_cap;
 
+  for (uint32_t k = (uint32_t)lane; k < a.stage_cap; k += kWave) s_stage[k] = 0;
   if (kLdsTables) {
     for (int i = (int)threadIdx.x; i < P; i += (int)blockDim.x) {
       s_price[i] = (PriceT)a.price[i];
@@ -121,147 +314,66 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
 
   if (t0 < t1) {
     const long long n_full = a.n_lines / kTile;      // tiles [0, n_full) are complete
-    uint32_t st = 0;
-    int carry_id = a.order_id[t0 * kTile];          // the wave's run starts inside this order
-    long long carry_sum = 0;
-    bool first_open = true;                          // no order has closed yet in this run
-    const int head_id = carry_id;
-    long long head_sum = 0;
+    const long long tf = t1 < n_full ? t1 : n_full;  // this wave's complete tiles are [t0, tf)
+    WaveRun o;
+    o.id = a.order_id[t0 * kTile];                   // the wave's run starts inside this order
+    o.sum = 0;
+    o.first_open = true;
+    o.head_sum = 0;
+    o.st = 0;
+    o.buf_base = (uint32_t)o.id - (uint32_t)a.base;
+    const int head_id = o.id;
 
-    auto load_tile = [&](long long t, int4& vid, int4& vpr, int4& vq) {
-      const long long l0 = t * kTile + (long long)lane * kLinesPerLane;
-      if (t < n_full) {
-        vid = *reinterpret_cast<const int4*>(a.order_id + l0);
-        vpr = *reinterpret_cast<const int4*>(a.product_idx + l0);
-        vq = *reinterpret_cast<const int4*>(a.qty + l0);
-      } else {
-        // last, partial tile: lines past the end repeat the last order id and carry nothing
-        const int last_id = a.order_id[a.n_lines - 1];
-        int ids[4], prs[4], qs[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const long long l = l0 + i;
-          const bool in = l < a.n_lines;
-          ids[i] = in ? a.order_id[l] : last_id;
-          prs[i] = in ? a.product_idx[l] : -1;
-          qs[i] = in ? a.qty[l] : 0;
-        }
-        vid = make_int4(ids[0], ids[1], ids[2], ids[3]);
-        vpr = make_int4(prs[0], prs[1], prs[2], prs[3]);
-        vq = make_int4(qs[0], qs[1], qs[2], qs[3]);
+    if (t0 < tf) {
+      // software pipeline: the next tile's three 16-byte loads are in flight while this tile is
+      // processed.  The last iteration re-loads its own tile instead of branching around the load.
+      const int32_t* p_id = a.order_id + t0 * kTile + lane * kLinesPerLane;
+      const int32_t* p_pr = a.product_idx + t0 * kTile + lane * kLinesPerLane;
+      const int32_t* p_q = a.qty + t0 * kTile + lane * kLinesPerLane;
+      int4 cid = load_stream16(p_id);
+      int4 cpr = load_stream16(p_pr);
+      int4 cq = load_stream16(p_q);
+      for (long long t = t0; t < tf; ++t) {
+        const long long step = (t + 1 < tf) ? kTile : 0;
+        p_id += step; p_pr += step; p_q += step;
+        const int4 nid = load_stream16(p_id);
+        const int4 npr = load_stream16(p_pr);
+        const int4 nq = load_stream16(p_q);
+        const int ids[4] = {cid.x, cid.y, cid.z, cid.w};
+        const int prs[4] = {cpr.x, cpr.y, cpr.z, cpr.w};
+        const int qs[4] = {cq.x, cq.y, cq.z, cq.w};
+        lines_tile<PriceT, kLdsTables>(a, s_price, s_hist, s_stage, s_dummy, ids, prs, qs, lane, o);
+        cid = nid; cpr = npr; cq = nq;
       }
-    };
-
-    int4 cid, cpr, cq;
-    load_tile(t0, cid, cpr, cq);
-
-    for (long long t = t0; t < t1; ++t) {
-      int4 nid = cid, npr = cpr, nq = cq;
-      if (t + 1 < t1) load_tile(t + 1, nid, npr, nq);       // next tile's loads fly during this tile
-
-      const int ids[4] = {cid.x, cid.y, cid.z, cid.w};
-      const int prs[4] = {cpr.x, cpr.y, cpr.z, cpr.w};
-      const int qs[4] = {cq.x, cq.y, cq.z, cq.w};
-
-      // price gather, line value, stock delta
-      long long v[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool valid = (uint32_t)prs[i] < (uint32_t)P;
-        const int pi = valid ? prs[i] : 0;
-        long long price;
-        if (kLdsTables) price = (long long)s_price[pi];
-        else price = (long long)a.price[pi];
-        v[i] = valid ? price * (long long)qs[i] : 0ll;
-        if (valid) {
-          if (kLdsTables) split_add32(&s_hist[pi], &a.prod_carry[pi], qs[i]);
-          else atomicAdd(&a.prod_carry[pi], (unsigned long long)(long long)qs[i]);
-        }
-      }
-
-      // order boundaries inside the lane's four lines
-      int prev = __shfl_up(ids[3], 1);
-      if (lane == 0) prev = carry_id;
-      const bool h0 = ids[0] != prev, h1 = ids[1] != ids[0], h2 = ids[2] != ids[1], h3 = ids[3] != ids[2];
-      const bool has_head = h0 | h1 | h2 | h3;
-      const long long tot = v[0] + v[1] + v[2] + v[3];
-      // pre: lines before the lane's first boundary (they continue the incoming order)
-      long long pre = 0;
-      {
-        bool open = true;
-        open &= !h0; pre += open ? v[0] : 0;
-        open &= !h1; pre += open ? v[1] : 0;
-        open &= !h2; pre += open ? v[2] : 0;
-        open &= !h3; pre += open ? v[3] : 0;
-      }
-      // tail: lines from the lane's last boundary on
-      long long tail = v[3];
-      {
-        bool open = !h3;
-        tail += open ? v[2] : 0; open &= !h2;
-        tail += open ? v[1] : 0; open &= !h1;
-        tail += open ? v[0] : 0;
-      }
-
-      // incoming[l] = sum of the open order's lines that precede lane l (incl. the carry)
-      const long long incl = wave_inclusive_scan(tot, lane);
-      const long long excl = incl - tot;
-      const unsigned long long headmask = __ballot(has_head);
-      const unsigned long long below = headmask & ((1ull << lane) - 1ull);
-      const int j = below ? (63 - __clzll((long long)below)) : 0;
-      const long long gj = __shfl(tail - incl, j);              // tail[j] - incl[j]
-      const long long incoming = excl + (below ? gj : carry_sum);
-
-      if (first_open && headmask != 0ull) {                       // wave-uniform, once per run
-        const int L = __ffsll((long long)headmask) - 1;
-        head_sum = __shfl(incoming + pre, L);
-        first_open = false;
-      }
-
-      // close orders at every boundary: the lane that sees order b start writes order a's total
-      long long run = incoming;
-      bool gap = false;
-      int pid = prev;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool h = ids[i] != pid;
-        if (h) {
-          const uint32_t idx = (uint32_t)pid - (uint32_t)a.base;
-          if (idx < (uint32_t)a.n_orders) a.order_total[idx] = run; else st |= kStOrderRange;
-          if (ids[i] < pid) st |= kStUnsorted;
-          else if ((uint32_t)ids[i] - (uint32_t)pid > 1u) gap = true;
-          run = 0;
-        }
-        run += v[i];
-        pid = ids[i];
-      }
-      unsigned long long gm = __ballot(gap);
-      while (gm) {                                               // orders with no lines: rare
-        const int L = __ffsll((long long)gm) - 1;
-        gm &= gm - 1ull;
-        const int p0 = __shfl(prev, L), b0 = __shfl(ids[0], L), b1 = __shfl(ids[1], L),
-                  b2 = __shfl(ids[2], L), b3 = __shfl(ids[3], L);
-        wave_fill_gap(a, p0, b0, lane);
-        wave_fill_gap(a, b0, b1, lane);
-        wave_fill_gap(a, b1, b2, lane);
-        wave_fill_gap(a, b2, b3, lane);
-      }
-
-      carry_id = __shfl(ids[3], kWave - 1);
-      carry_sum = __shfl(run, kWave - 1);
-      cid = nid; cpr = npr; cq = nq;
     }
+    if (tf < t1) {
+      // the data set's last, partial tile: lines past the end repeat the last order id, add nothing
+      const long long l0 = tf * kTile + (long long)lane * kLinesPerLane;
+      const int last_id = a.order_id[a.n_lines - 1];
+      int ids[4], prs[4], qs[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long l = l0 + i;
+        const bool in = l < a.n_lines;
+        ids[i] = in ? a.order_id[l] : last_id;
+        prs[i] = in ? a.product_idx[l] : -1;
+        qs[i] = in ? a.qty[l] : 0;
+      }
+      lines_tile<PriceT, kLdsTables>(a, s_price, s_hist, s_stage, s_dummy, ids, prs, qs, lane, o);
+    }
+    // orders closed since the last flush (everything below the order that is still open)
+    stage_flush(a, s_stage, o, min(((uint32_t)o.id - (uint32_t)a.base) - o.buf_base, a.stage_cap), lane);
 
     // the run's first and last order may continue in the neighbouring waves: hand both to k_fixup
     if (lane == 0) {
-      const uint32_t idx = (uint32_t)carry_id - (uint32_t)a.base;
-      if (idx >= (uint32_t)a.n_orders) st |= kStOrderRange;
+      const uint32_t idx = (uint32_t)o.id - (uint32_t)a.base;
+      if (idx >= (uint32_t)a.n_orders) o.st |= kStOrderRange;
       a.rec_id[2 * g] = head_id;
-      a.rec_id[2 * g + 1] = carry_id;
-      if (first_open) { a.rec_sum[2 * g] = carry_sum; a.rec_sum[2 * g + 1] = 0; }
-      else            { a.rec_sum[2 * g] = head_sum;  a.rec_sum[2 * g + 1] = carry_sum; }
+      a.rec_id[2 * g + 1] = o.id;
+      if (o.first_open) { a.rec_sum[2 * g] = o.sum; a.rec_sum[2 * g + 1] = 0; }
+      else              { a.rec_sum[2 * g] = o.head_sum; a.rec_sum[2 * g + 1] = o.sum; }
     }
-    if (st) atomicOr(a.status, st);
+    if (o.st) atomicOr(a.status, o.st);
   }
 
   if (kLdsTables) {
@@ -359,7 +471,7 @@ __global__ void __launch_bounds__(kFixThreads) k_fixup(FixArgs a) {
     }
   }
   // block scans: exclusive sum of tsum, exclusive running max of tmax
-  long long incl = wave_inclusive_scan(tsum, lane);
+  long long incl = wave_inclusive_scan(tsum);
   int mx = tmax;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(mx, d); if (lane >= d) mx = max(mx, t); }
