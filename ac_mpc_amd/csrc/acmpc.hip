@@ -172,10 +172,11 @@ struct CustPlan {
 void plan_customers(const acmpc_ctx* ctx, int64_t n_orders, int32_t n_customers, CustPlan* p) {
   p->threads = ctx->k2_threads;
   const int slots = std::max(1, ctx->n_cu / 8);             // workgroups per XCD label, one per CU
-  const int max_span = (128 * 1024) / 4;                    // 128 KiB of 32-bit partials
-  int r = 1;
-  while ((int64_t)r * max_span < n_customers && r < 64) r <<= 1;
-  p->lds_tables = !ctx->force_global_tables && r <= slots && (int64_t)r * max_span >= n_customers;
+  // Every sibling workgroup of a stream re-reads the stream's orders through L2, so the number of
+  // customer ranges R is kept as small as the LDS allows: 32-bit partial sums, one workgroup's LDS.
+  const int64_t max_span = ((int64_t)kMaxLds - kLdsReserve - kWave * 4) / 4;
+  const int64_t r64 = std::max<int64_t>(1, (n_customers + max_span - 1) / max_span);
+  p->lds_tables = !ctx->force_global_tables && r64 <= slots;
   p->n_tiles = (n_orders + kTile - 1) / kTile;
   p->c_pad = (n_customers + 3) & ~3;
   if (!p->lds_tables) {
@@ -186,10 +187,11 @@ void plan_customers(const acmpc_ctx* ctx, int64_t n_orders, int32_t n_customers,
     const int groups = (int)std::min<int64_t>(slots, want);
     p->n_streams = 8 * groups;
   } else {
+    const int r = (int)r64;
     p->n_ranges = r;
     p->span = (n_customers + r - 1) / r;
     p->span = (p->span + 3) & ~3;
-    p->lds_bytes = (size_t)p->span * 4;
+    p->lds_bytes = (size_t)p->span * 4 + kWave * 4;      // partial sums + one scratch word per lane
     const int max_groups = std::max(1, slots / r);
     // small inputs: fewer streams, so that every stream still has a few tiles per wave
     const int64_t want = std::max<int64_t>(1, (p->n_tiles + 8 * 32 - 1) / (8 * 32));
@@ -317,9 +319,10 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     c.n_customers = n_customers; c.c_pad = cp.c_pad; c.span = cp.span; c.n_ranges = cp.n_ranges;
     c.n_streams = cp.n_streams; c.cust_slab = ctx->d_cust_slab.p; c.cust_carry = ctx->d_cust_carry.p;
     c.status = ctx->d_status;
+    c.ablate = env_int("ACMPC_K2_ABLATE", 0);
     ctx->carry_dirty = true;
     if (cp.lds_tables) {
-      if (cp.lds_bytes > 48 * 1024 && (rc = set_dyn_lds(ctx, k_customers<true>, cp.lds_bytes))) return rc;
+      if ((rc = set_dyn_lds(ctx, k_customers<true>, cp.lds_bytes))) return rc;
       hipLaunchKernelGGL(k_customers<true>, dim3(cp.blocks), dim3(cp.threads), cp.lds_bytes, st, c);
     } else {
       hipLaunchKernelGGL(k_customers<false>, dim3(cp.blocks), dim3(cp.threads), 0, st, c);

@@ -153,6 +153,63 @@ __global__ void __launch_bounds__(256) k_copy8(const int2* __restrict__ src, int
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+// k_customers read pattern: R sibling workgroups (same blockIdx % 8) read the same stream of orders
+// (4 B + 8 B per order), waves of a workgroup take tiles round-robin, DEPTH tiles in flight.
+template <int DEPTH, bool NT>
+__global__ void __launch_bounds__(1024) k_sib(const int* __restrict__ c, const long long* __restrict__ tot,
+                                              long long n_tiles, int R, int n_streams, int* sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int s = x + 8 * (j / R);
+  const long long per = (n_tiles + n_streams - 1) / n_streams;
+  const long long t0 = s * per;
+  long long t1 = t0 + per; if (t1 > n_tiles) t1 = n_tiles;
+  long long t = t0 + wave;
+  if (t >= t1) return;
+  const long long last = t + ((t1 - 1 - t) / wpb) * wpb;
+  int4 rc[DEPTH]; longlong2 ra[DEPTH], rb[DEPTH];
+  auto ld = [&](int d, long long tt) {
+    if (tt > last) tt = last;
+    if (NT) {
+      rc[d] = ntload4(c + tt * kTile + lane * 4);
+      const int4 u = ntload4(reinterpret_cast<const int*>(tot + tt * kTile + lane * 4));
+      const int4 w = ntload4(reinterpret_cast<const int*>(tot + tt * kTile + lane * 4 + 2));
+      ra[d].x = u.x; ra[d].y = u.z; rb[d].x = w.x; rb[d].y = w.z;
+    } else {
+      rc[d] = *reinterpret_cast<const int4*>(c + tt * kTile + lane * 4);
+      ra[d] = *reinterpret_cast<const longlong2*>(tot + tt * kTile + lane * 4);
+      rb[d] = *reinterpret_cast<const longlong2*>(tot + tt * kTile + lane * 4 + 2);
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) ld(d, t + (long long)d * wpb);
+  int acc = 0;
+  for (; t <= last; t += (long long)DEPTH * wpb) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int4 cc = rc[d]; const longlong2 a2 = ra[d], b2 = rb[d];
+      ld(d, t + (long long)(d + DEPTH) * wpb);
+      acc += cc.x ^ cc.y ^ cc.z ^ cc.w ^ (int)a2.x ^ (int)a2.y ^ (int)b2.x ^ (int)b2.y;
+    }
+  }
+  if (acc == 0x7fffffff) *sink = acc;
+}
+
+template <int DEPTH, bool NT>
+void run_sib(int R, int blocks, int threads, const int* c, const long long* tot, long long m, int* sink) {
+  const long long n_tiles = m / kTile;
+  const int n_streams = blocks / R;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((k_sib<DEPTH, NT>), dim3(blocks), dim3(threads), 0, 0, c, tot, n_tiles, R, n_streams, sink);
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k_sib<DEPTH, NT>), dim3(blocks), dim3(threads), 0, 0, c, tot, n_tiles, R, n_streams, sink);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+  printf("siblings R=%d depth=%d nt=%d blocks %d x %d: %.3f ms  (%.2f TB/s of unique bytes, %.2f TB/s through L1)\n", R, DEPTH, (int)NT,
+         blocks, threads, ms, 12.0 * m / ms / 1e9, 12.0 * m * R / ms / 1e9);
+}
+
 template <int MODE, int DEPTH, int WRITE>
 void run(const char* name, int blocks, int threads, const int* a, const int* b, const int* c, long long n,
          long long* out, int* sink) {
@@ -179,6 +236,14 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&a, n * 4 + 4096)); CK(hipMalloc(&b, n * 4 + 4096)); CK(hipMalloc(&c, n * 4 + 4096));
   CK(hipMalloc(&out, n / 4 * 8 + 4096)); CK(hipMalloc(&sink, 4));
   CK(hipMemset(a, 1, n * 4)); CK(hipMemset(b, 2, n * 4)); CK(hipMemset(c, 3, n * 4));
+  {
+    const long long m = n / 4;
+    for (int R : {1, 2, 4}) { run_sib<1, false>(R, 256, 1024, a, out, m, sink); run_sib<4, false>(R, 256, 1024, a, out, m, sink); run_sib<4, true>(R, 256, 1024, a, out, m, sink); }
+    run_sib<2, false>(4, 256, 512, a, out, m, sink);
+    run_sib<4, false>(4, 512, 512, a, out, m, sink);
+    run_sib<4, false>(8, 512, 512, a, out, m, sink);
+  }
+  if (argc > 2) return 0;
 #define RUN(M, D, W, BL, TH) run<M, D, W>(#M "/" #D " write-mode " #W, BL, TH, a, b, c, n, out, sink);
   RUN(0, 1, 0, 256, 1024) RUN(0, 1, 1, 256, 1024) RUN(0, 1, 2, 256, 1024) RUN(0, 1, 3, 256, 1024)
   RUN(0, 1, 4, 256, 1024) RUN(0, 1, 5, 256, 1024) RUN(0, 1, 6, 256, 1024)
