@@ -675,9 +675,10 @@ __global__ void __launch_bounds__(1024) k_customers(CustArgs a) {
     }
     (void)stride;
   }
-  if (tf < t1 && wave == 0) {
-    // the last, partial tile of the order columns: orders past the end are customer 0 with total 0
-    const long long o0 = tf * kTile + (long long)lane * 4;
+  if (wave == 0 && n_full < a.n_tiles && t0 <= n_full && n_full < t1) {
+    // the last, partial tile of the order columns (it belongs to exactly one stream): orders past
+    // the end are customer 0 with total 0
+    const long long o0 = n_full * kTile + (long long)lane * 4;
     int cs[4];
     long long tv[4];
 #pragma unroll
