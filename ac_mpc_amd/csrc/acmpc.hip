@@ -60,6 +60,7 @@ struct acmpc_ctx {
   // tuning (environment overrides, read once)
   int k1_threads = 1024;
   int k1_blocks_per_cu = 1;
+  int k1_lpl = 4;
   int k2_threads = 1024;
   int force_global_tables = 0;
 
@@ -125,26 +126,31 @@ struct LinesPlan {
   bool price32;
   size_t lds_bytes;
   int threads, blocks, waves_per_block;
-  uint32_t stage_cap;
+  int lpl;                 // lines per lane per tile (4 or 8)
+  int tile_lines;
+  uint32_t stage_cap, flush_reserve;
   int64_t n_tiles, tiles_per_wave;
   int n_active_waves;
 };
 
 int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p) {
+  // tables hold P + 1 entries (the null product): int32 or int64 prices + 32-bit histogram
   const size_t need32 = (size_t)ctx->p_pad * 8, need64 = (size_t)ctx->p_pad * 12;
   p->price32 = ctx->price_fits32;
   p->lds_bytes = p->price32 ? need32 : need64;
   p->threads = ctx->k1_threads;
   p->waves_per_block = p->threads / kWave;
-  // besides the tables every wave stages finished order totals: at least 256 slots of 8 bytes
-  const size_t min_stage = (size_t)p->waves_per_block * kTile * 8 + kWave * 8;
-  p->lds_tables = !ctx->force_global_tables && p->lds_bytes + min_stage + kLdsReserve <= (size_t)kMaxLds;
-  if (!p->lds_tables) { p->lds_bytes = 0; p->price32 = false; }
+  p->lpl = (p->price32 && ctx->k1_lpl == 8) ? 8 : 4;
+  p->tile_lines = kWave * p->lpl;
+  // besides the tables every wave stages finished order totals: stage_cap slots + 64 scratch slots
+  auto stage_bytes = [&](uint32_t cap) { return (size_t)p->waves_per_block * (cap + kWave) * 8; };
+  p->lds_tables = !ctx->force_global_tables && p->lds_bytes + stage_bytes(kTile) + kLdsReserve <= (size_t)kMaxLds;
+  if (!p->lds_tables) { p->lds_bytes = 0; p->price32 = false; p->lpl = 4; p->tile_lines = kTile; }
   p->stage_cap = 512;
-  while (p->stage_cap > kTile &&
-         p->lds_bytes + (size_t)p->waves_per_block * p->stage_cap * 8 + kWave * 8 + kLdsReserve > (size_t)kMaxLds)
+  while (p->stage_cap > (uint32_t)kTile && p->lds_bytes + stage_bytes(p->stage_cap) + kLdsReserve > (size_t)kMaxLds)
     p->stage_cap >>= 1;
-  p->lds_bytes += (size_t)p->waves_per_block * p->stage_cap * 8 + kWave * 8;
+  p->flush_reserve = std::min<uint32_t>((uint32_t)p->tile_lines, p->stage_cap / 2);
+  p->lds_bytes += stage_bytes(p->stage_cap);
   int bpc = ctx->k1_blocks_per_cu;
   {
     const int fit = (int)((size_t)kMaxLds / (p->lds_bytes + kLdsReserve));
@@ -153,7 +159,7 @@ int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p) {
   bpc = std::max(1, std::min(bpc, 2048 / p->threads));
   int max_blocks = ctx->n_cu * bpc;
   max_blocks = std::min(max_blocks, kMaxWavesTotal / p->waves_per_block);
-  p->n_tiles = (n_lines + kTile - 1) / kTile;
+  p->n_tiles = (n_lines + p->tile_lines - 1) / p->tile_lines;
   const int64_t max_waves = (int64_t)max_blocks * p->waves_per_block;
   p->tiles_per_wave = std::max<int64_t>(1, (p->n_tiles + max_waves - 1) / max_waves);
   p->n_active_waves = (int)((p->n_tiles + p->tiles_per_wave - 1) / p->tiles_per_wave);
@@ -211,9 +217,9 @@ int clear_carries(acmpc_ctx* ctx, hipStream_t st) {
   return ACMPC_OK;
 }
 
-template <typename PriceT, bool kLds>
+template <typename PriceT, bool kLds, int LPL>
 int launch_lines(acmpc_ctx* ctx, const LinesPlan& pl, const LinesArgs& a, hipStream_t st) {
-  auto kern = k_lines<PriceT, kLds>;
+  auto kern = k_lines<PriceT, kLds, LPL>;
   {
     int rc = set_dyn_lds(ctx, kern, pl.lds_bytes);
     if (rc) return rc;
@@ -269,18 +275,21 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.price = ctx->d_price.p; a.n_products = P; a.p_pad = ctx->p_pad;
     {
       // a workgroup adds at most lines_per_block quantities below q_small into a 32-bit cell
-      const uint64_t lines_per_block = (uint64_t)lp.tiles_per_wave * kTile * lp.waves_per_block;
+      const uint64_t lines_per_block = (uint64_t)lp.tiles_per_wave * lp.tile_lines * lp.waves_per_block;
       const uint64_t lim = 0xffffffffull / std::max<uint64_t>(1, lines_per_block);
       a.q_small = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(65536, lim));
       a.stage_cap = lp.stage_cap;
+      a.flush_reserve = lp.flush_reserve;
+      a.tile_lines = lp.tile_lines;
     }
     a.order_total = d_tot; a.prod_slab = ctx->d_prod_slab.p; a.prod_carry = ctx->d_prod_carry.p;
     a.rec_id = ctx->d_rec_id.p; a.rec_sum = ctx->d_rec_sum.p; a.status = ctx->d_status;
 
     ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
-    if (!lp.lds_tables) rc = launch_lines<int64_t, false>(ctx, lp, a, st);
-    else if (lp.price32) rc = launch_lines<int32_t, true>(ctx, lp, a, st);
-    else rc = launch_lines<int64_t, true>(ctx, lp, a, st);
+    if (!lp.lds_tables) rc = launch_lines<int64_t, false, 4>(ctx, lp, a, st);
+    else if (lp.price32 && lp.lpl == 8) rc = launch_lines<int32_t, true, 8>(ctx, lp, a, st);
+    else if (lp.price32) rc = launch_lines<int32_t, true, 4>(ctx, lp, a, st);
+    else rc = launch_lines<int64_t, true, 4>(ctx, lp, a, st);
     if (rc) return rc;
     if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
 
@@ -409,6 +418,7 @@ ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
   ctx->k1_threads = env_int("ACMPC_K1_THREADS", 1024);
   if (ctx->k1_threads != 256 && ctx->k1_threads != 512 && ctx->k1_threads != 1024) ctx->k1_threads = 1024;
   ctx->k1_blocks_per_cu = std::max(1, env_int("ACMPC_K1_BPC", 1));
+  ctx->k1_lpl = env_int("ACMPC_K1_LPL", 4);
   ctx->k2_threads = env_int("ACMPC_K2_THREADS", 1024);
   if (ctx->k2_threads != 256 && ctx->k2_threads != 512 && ctx->k2_threads != 1024) ctx->k2_threads = 1024;
   ctx->force_global_tables = env_int("ACMPC_FORCE_GLOBAL_TABLES", 0);
@@ -444,15 +454,16 @@ ACMPC_API int acmpc_set_products(acmpc_ctx* ctx, const int64_t* price_cents, int
   if (!price_cents || n_products <= 0) return fail(ctx, ACMPC_E_INVALID, "acmpc_set_products: empty product table");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipDeviceSynchronize());          // nothing may still be reading the old table
-  int rc = ensure(ctx, ctx->d_price, (size_t)n_products);
+  int rc = ensure(ctx, ctx->d_price, (size_t)n_products + 1);
   if (rc) return rc;
   HIPCHK(ctx, hipMemcpy(ctx->d_price.p, price_cents, (size_t)n_products * 8, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemset(ctx->d_price.p + n_products, 0, 8));      // the null product: price 0
   bool fits = true;
   for (int32_t i = 0; i < n_products; ++i)
     if (price_cents[i] < INT32_MIN || price_cents[i] > INT32_MAX) { fits = false; break; }
   ctx->price_fits32 = fits;
   ctx->n_products = n_products;
-  ctx->p_pad = (n_products + 3) & ~3;
+  ctx->p_pad = (n_products + 1 + 3) & ~3;                         // tables hold the null product too
   // the carry workspace is indexed by product: start it clean at the new size
   release(ctx->d_prod_carry);
   if ((rc = ensure(ctx, ctx->d_prod_carry, (size_t)ctx->p_pad, true))) return rc;

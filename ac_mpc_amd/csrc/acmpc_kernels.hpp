@@ -32,6 +32,7 @@ constexpr int kMaxWavesTotal = 4096;              // k_lines waves; two records 
 constexpr int kFixThreads = 1024;
 constexpr int kFixStrip = 8;                      // records per thread in k_fixup block 0
 constexpr int kMergeProducts = 64;                // products per merge block in k_fixup
+constexpr int kLinesDepth = 1;                    // line tiles in flight per wave in k_lines
 constexpr int kCustDepth = 4;                     // order tiles in flight per wave in k_customers
 
 constexpr uint32_t kStOrderRange = 1u, kStUnsorted = 2u, kStCustomerRange = 4u;
@@ -41,15 +42,17 @@ struct LinesArgs {
   const int32_t* product_idx;
   const int32_t* qty;
   int64_t n_lines;
-  int64_t n_tiles;          // ceil(n_lines / 256)
+  int64_t n_tiles;          // ceil(n_lines / tile_lines)
   int64_t tiles_per_wave;
   int32_t base;             // order_id_base
   int32_t n_orders;         // M
-  const int64_t* price;     // [P] device
+  const int64_t* price;     // [P + 1] device; entry P is 0 (the null product)
   int32_t n_products;
-  int32_t p_pad;            // P rounded up to a multiple of 4
+  int32_t p_pad;            // P + 1 rounded up to a multiple of 4
   uint32_t q_small;         // quantities in [0, q_small) use the 32-bit LDS histogram
   uint32_t stage_cap;       // staging slots per wave (orders buffered in LDS before they are written)
+  uint32_t flush_reserve;   // flush when fewer than this many slots are left (lines per tile)
+  int64_t tile_lines;       // 64 * lines per lane
   int64_t* order_total;     // [M]
   uint32_t* prod_slab;      // [gridDim.x][p_pad] low words of the per-workgroup stock deltas
   unsigned long long* prod_carry;   // [P] high-word corrections (LDS mode) / product_qty itself (global mode)
@@ -68,26 +71,38 @@ __device__ __forceinline__ int4 load_stream16(const int32_t* p) {
   return make_int4(v.x, v.y, v.z, v.w);
 }
 
-// One Hillis-Steele step of a 64-bit wave scan through DPP (no LDS traffic, no waits).
-template <int kCtrl, int kRowMask>
-__device__ __forceinline__ long long dpp_scan_step(long long v) {
-  const int lo = (int)v, hi = (int)(v >> 32);
-  const int slo = __builtin_amdgcn_update_dpp(0, lo, kCtrl, kRowMask, 0xf, false);
-  const int shi = __builtin_amdgcn_update_dpp(0, hi, kCtrl, kRowMask, 0xf, false);
-  return v + (long long)(((unsigned long long)(unsigned int)shi << 32) | (unsigned int)slo);
-}
-
-// Inclusive prefix sum over the 64 lanes: row_shr 1,2,4,8 inside each 16-lane row, then the row
-// totals are broadcast into the following rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into
-// rows 2 and 3).
+// Inclusive prefix sum of a 64-bit value over the 64 lanes, entirely in DPP adds with carry (no LDS
+// traffic, no waits): row_shr 1,2,4,8 inside each 16-lane row, then the row totals are broadcast
+// into the following rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).
+// Each step is v_add_co_u32 / v_addc_co_u32 with the DPP operand on the running value itself.
+// hipcc does not see inside an asm block, so the two wait states a DPP read needs after a VALU
+// write of the same register are spelled out as s_nop.
 __device__ __forceinline__ long long wave_inclusive_scan(long long v) {
-  v = dpp_scan_step<0x111, 0xf>(v);
-  v = dpp_scan_step<0x112, 0xf>(v);
-  v = dpp_scan_step<0x114, 0xf>(v);
-  v = dpp_scan_step<0x118, 0xf>(v);
-  v = dpp_scan_step<0x142, 0xa>(v);
-  v = dpp_scan_step<0x143, 0xc>(v);
-  return v;
+  unsigned int lo = (unsigned int)v, hi = (unsigned int)((unsigned long long)v >> 32);
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_co_u32_dpp %0, vcc, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 0\n\t"
+      "v_add_co_u32_dpp %0, vcc, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 0\n\t"
+      "v_add_co_u32_dpp %0, vcc, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 0\n\t"
+      "v_add_co_u32_dpp %0, vcc, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 0\n\t"
+      "v_add_co_u32_dpp %0, vcc, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_co_u32_dpp %0, vcc, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      : "+v"(lo), "+v"(hi)
+      :
+      : "vcc");
+  return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
 // Value of lane-1 (lane 0 receives `first`).
@@ -144,125 +159,133 @@ __device__ __forceinline__ void stage_flush(const LinesArgs& a, long long* s_sta
   o.buf_base += n;
 }
 
-// One 256-line tile: lane l holds lines 4l..4l+3 of the tile in (ids, prs, qs).
-template <typename PriceT, bool kLdsTables>
+// One tile of 64 * LPL lines: lane l holds lines LPL*l .. LPL*l+LPL-1 of the tile in (ids, prs, qs).
+//
+// Tables carry one extra entry, index P, the "null product": price 0 and a scratch histogram
+// cell.  Any product_idx outside [0, P) is clamped to it with one unsigned min, so unknown codes
+// need no branch and add nothing.
+template <typename PriceT, bool kLdsTables, int LPL>
 __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_price, uint32_t* s_hist,
-                                           long long* s_stage, long long* s_dummy,
-                                           const int (&ids)[4], const int (&prs)[4], const int (&qs)[4],
-                                           int lane, WaveRun& o) {
+                                           long long* s_stage, const int (&ids)[LPL], const int (&prs)[LPL],
+                                           const int (&qs)[LPL], int lane, uint32_t lt_lo, uint32_t lt_hi,
+                                           WaveRun& o) {
   const uint32_t P = (uint32_t)a.n_products;
-  // price gather, line value, stock delta.  Quantities in [0, q_small) go to the 32-bit LDS
-  // histogram with a non-returning add (the host sizes q_small so that a workgroup's sum cannot
-  // wrap); anything else (negative or huge, never produced by the reference) goes to a 64-bit
-  // global atomic.
-  long long v[4];
-  bool valid[4];
-  int pi[4];
+  uint32_t pi[LPL];
+  long long v[LPL];
+  uint32_t qmax = 0;               // largest quantity (as unsigned) seen by this lane
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    valid[i] = (uint32_t)prs[i] < P;
-    pi[i] = valid[i] ? prs[i] : 0;
-  }
-  long long price[4];
+  for (int i = 0; i < LPL; ++i) pi[i] = min((uint32_t)prs[i], P);
+  if (kLdsTables) {
+    PriceT price[LPL];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (kLdsTables) price[i] = (long long)s_price[pi[i]];
-    else price[i] = (long long)a.price[pi[i]];
-  }
-  uint32_t rare = 0;                 // bit 0: a quantity needs the 64-bit path; bit 1: ids not sorted
+    for (int i = 0; i < LPL; ++i) price[i] = s_price[pi[i]];
+    // Stock delta: every quantity is added to the 32-bit LDS histogram with a non-returning add.
+    // The host sizes q_small so that a workgroup's sum of quantities below q_small cannot wrap; a
+    // quantity outside [0, q_small) (never produced by the reference, which always writes 1) is
+    // detected through qmax, taken back out of the histogram and sent to a 64-bit global atomic.
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (kLdsTables) {
-      const bool small = (uint32_t)qs[i] < a.q_small;
-      const uint32_t add = (valid[i] && small) ? (uint32_t)qs[i] : 0u;
-      __hip_atomic_fetch_add(&s_hist[pi[i]], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      rare |= (valid[i] && !small) ? 1u : 0u;
-    } else {
-      rare |= valid[i] ? 1u : 0u;
+    for (int i = 0; i < LPL; ++i) {
+      __hip_atomic_fetch_add(&s_hist[pi[i]], (uint32_t)qs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      qmax = max(qmax, (uint32_t)qs[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < LPL; ++i) v[i] = (long long)price[i] * (long long)qs[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < LPL; ++i) {
+      v[i] = a.price[pi[i]] * (long long)qs[i];
+      if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qs[i]);
     }
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = valid[i] ? price[i] * (long long)qs[i] : 0ll;
 
-  // order boundaries inside the lane's four lines
-  const int prev = wave_shift_up1(ids[3], o.id);
-  const bool h0 = ids[0] != prev, h1 = ids[1] != ids[0], h2 = ids[2] != ids[1], h3 = ids[3] != ids[2];
-  const bool has_head = h0 | h1 | h2 | h3;
-  rare |= (ids[0] < prev || ids[1] < ids[0] || ids[2] < ids[1] || ids[3] < ids[2]) ? 2u : 0u;
-  const long long tot = v[0] + v[1] + v[2] + v[3];
-  // tail: the lane's lines from its last boundary on
-  long long tail = v[3];
-  {
-    bool open = !h3;
-    tail += open ? v[2] : 0; open &= !h2;
-    tail += open ? v[1] : 0; open &= !h1;
-    tail += open ? v[0] : 0;
+  // order boundaries inside the lane's lines: d[i] != 0 where line i starts a new order
+  const int prev = wave_shift_up1(ids[LPL - 1], o.id);
+  int d[LPL];
+  d[0] = ids[0] - prev;
+#pragma unroll
+  for (int i = 1; i < LPL; ++i) d[i] = ids[i] - ids[i - 1];
+  int dmin = d[0], dor = d[0];
+#pragma unroll
+  for (int i = 1; i < LPL; ++i) { dmin = min(dmin, d[i]); dor |= d[i]; }
+  // r: sum of the lane's lines since its last boundary (all of them if it has none); tot: all of them
+  long long r = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < LPL; ++i) {
+    r = d[i] ? 0ll : r;
+    r += v[i];
+    tot += v[i];
   }
   // incoming[l] = partial total, at the start of lane l, of the order that is open there:
   // everything since the nearest boundary in a lower lane, or the carry plus everything so far.
   const long long incl = wave_inclusive_scan(tot);
   const long long excl = incl - tot;
-  const unsigned long long headmask = __ballot(has_head);
-  const unsigned long long below = headmask & ((1ull << lane) - 1ull);
-  const int j = below ? (63 - __clzll((long long)below)) : 0;
-  const long long gj = __shfl(tail - incl, j);              // tail[j] - incl[j]
-  const long long incoming = excl + (below ? gj : o.sum);
+  const unsigned long long headmask = __ballot(dor != 0);
+  const uint32_t below_lo = (uint32_t)headmask & lt_lo, below_hi = (uint32_t)(headmask >> 32) & lt_hi;
+  const bool any_below = (below_lo | below_hi) != 0u;
+  const int j = below_hi ? (63 - __clz(below_hi)) : (31 - __clz(below_lo | 1u));
+  const long long gj = __shfl(r - incl, j);                 // (sum since last boundary) - incl, of lane j
+  const long long incoming = excl + (any_below ? gj : o.sum);
 
   if (o.first_open && headmask != 0ull) {                     // wave-uniform, once per run
     // pre: lines of the first boundary lane that still belong to the run's first order
     long long pre = 0;
     bool open = true;
-    open &= !h0; pre += open ? v[0] : 0;
-    open &= !h1; pre += open ? v[1] : 0;
-    open &= !h2; pre += open ? v[2] : 0;
+#pragma unroll
+    for (int i = 0; i < LPL - 1; ++i) { open &= d[i] == 0; pre += open ? v[i] : 0ll; }
     const int L = __ffsll((long long)headmask) - 1;
     o.head_sum = readlane64(incoming + pre, L);
     o.first_open = false;
   }
 
-  const int new_id = __builtin_amdgcn_readlane(ids[3], kWave - 1);
+  const int new_id = __builtin_amdgcn_readlane(ids[LPL - 1], kWave - 1);
   const uint32_t span = ((uint32_t)new_id - (uint32_t)a.base) - o.buf_base;   // slots this tile can touch
-  const unsigned long long rare_mask = __ballot(rare != 0u);
+  const bool lane_rare = (kLdsTables && qmax >= a.q_small) || dmin < 0;
+  const unsigned long long rare_mask = __ballot(lane_rare);
   long long run = incoming;
   int pid = prev;
 
   if (rare_mask == 0ull && span <= a.stage_cap) {
-    // ---- common path: every order that closes in this tile goes to its staging slot; lanes without
-    // a boundary at line i write a scratch slot instead of branching.
+    // ---- common path: every order that closes in this tile goes to its staging slot; a lane whose
+    // line i is not a boundary writes its scratch slot (stage_cap + lane) instead of branching, and
+    // the same min() keeps any slot inside the wave's slice.
     const uint32_t off = (uint32_t)a.base + o.buf_base;
+    const uint32_t scratch = a.stage_cap + (uint32_t)lane;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool h = ids[i] != pid;
+    for (int i = 0; i < LPL; ++i) {
       const uint32_t slot = (uint32_t)pid - off;
-      long long* dst = (h && slot < a.stage_cap) ? (s_stage + slot) : (s_dummy + lane);
-      *dst = run;
-      run = h ? 0ll : run;
+      const uint32_t w = min(d[i] ? slot : 0xffffffffu, scratch);
+      s_stage[w] = run;
+      run = d[i] ? 0ll : run;
       run += v[i];
       pid = ids[i];
     }
     o.id = new_id;
     o.sum = readlane64(run, kWave - 1);
-    if (span > a.stage_cap - kTile) stage_flush(a, s_stage, o, span, lane);
+    if (span > a.stage_cap - a.flush_reserve) stage_flush(a, s_stage, o, span, lane);
     return;
   }
 
-  // ---- rare path: 64-bit quantities, unsorted ids, or a jump in order ids wider than the staging
-  // buffer.  Empty the buffer, then write this tile's orders (and the ids they skip) directly.
+  // ---- rare path: quantities outside [0, q_small), unsorted ids, or a jump in order ids wider than
+  // the staging buffer.  Empty the buffer, then write this tile's orders (and the ids they skip)
+  // directly.
   stage_flush(a, s_stage, o, min(((uint32_t)o.id - (uint32_t)a.base) - o.buf_base, a.stage_cap), lane);
-  if (rare & 1u) {
+  if (kLdsTables) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (valid[i] && (!kLdsTables || (uint32_t)qs[i] >= a.q_small))
-        atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qs[i]);
+    for (int i = 0; i < LPL; ++i) {
+      if ((uint32_t)qs[i] >= a.q_small) {
+        __hip_atomic_fetch_add(&s_hist[pi[i]], 0u - (uint32_t)qs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qs[i]);
+      }
+    }
   }
-  if (rare & 2u) o.st |= kStUnsorted;
   bool gap = false;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < LPL; ++i) {
     if (ids[i] != pid) {
       const uint32_t idx = (uint32_t)pid - (uint32_t)a.base;
       if (idx < (uint32_t)a.n_orders) a.order_total[idx] = run; else o.st |= kStOrderRange;
-      if (ids[i] >= pid && (uint32_t)ids[i] - (uint32_t)pid > 1u) gap = true;
+      if (ids[i] < pid) o.st |= kStUnsorted;
+      else if ((uint32_t)ids[i] - (uint32_t)pid > 1u) gap = true;
       run = 0;
     }
     run += v[i];
@@ -272,41 +295,54 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
   while (gm) {                                                 // orders with no lines
     const int L = __ffsll((long long)gm) - 1;
     gm &= gm - 1ull;
-    const int p0 = __builtin_amdgcn_readlane(prev, L), b0 = __builtin_amdgcn_readlane(ids[0], L),
-              b1 = __builtin_amdgcn_readlane(ids[1], L), b2 = __builtin_amdgcn_readlane(ids[2], L),
-              b3 = __builtin_amdgcn_readlane(ids[3], L);
-    wave_fill_gap(a, p0, b0, lane);
-    wave_fill_gap(a, b0, b1, lane);
-    wave_fill_gap(a, b1, b2, lane);
-    wave_fill_gap(a, b2, b3, lane);
+    int before = __builtin_amdgcn_readlane(prev, L);
+#pragma unroll
+    for (int i = 0; i < LPL; ++i) {
+      const int here = __builtin_amdgcn_readlane(ids[i], L);
+      wave_fill_gap(a, before, here, lane);
+      before = here;
+    }
   }
   o.id = new_id;
   o.sum = readlane64(run, kWave - 1);
   o.buf_base = (uint32_t)new_id - (uint32_t)a.base;            // staging restarts at the open order
 }
 
-template <typename PriceT, bool kLdsTables>
+// LPL consecutive int32 of one column for this lane, as 16-byte streaming loads.
+template <int LPL>
+__device__ __forceinline__ void load_lines(const int32_t* p, int (&out)[LPL]) {
+#pragma unroll
+  for (int k = 0; k < LPL / 4; ++k) {
+    const int4 x = load_stream16(p + 4 * k);
+    out[4 * k] = x.x; out[4 * k + 1] = x.y; out[4 * k + 2] = x.z; out[4 * k + 3] = x.w;
+  }
+}
+
+template <typename PriceT, bool kLdsTables, int LPL>
 __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
+  constexpr int kTileL = kWave * LPL;                 // lines per wave-tile
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
   const int waves_per_block = (int)(blockDim.x >> 6);
-  const int P = a.n_products;
-  // LDS: [price table][stock-delta histogram] (only with kLdsTables) [staging, one slice per wave][scratch]
+  const int P1 = a.n_products + 1;                    // tables include the null product
+  // LDS: [price table][stock-delta histogram] (only with kLdsTables), then per wave a staging slice
+  // of stage_cap slots followed by 64 scratch slots.
   const size_t tables = kLdsTables ? (size_t)a.p_pad * (sizeof(PriceT) + sizeof(uint32_t)) : 0;
   PriceT* s_price = reinterpret_cast<PriceT*>(smem);
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + (size_t)a.p_pad * sizeof(PriceT));
-  long long* s_stage = reinterpret_cast<long long*>(smem + tables) + (size_t)wave * a.stage_cap;
-  long long* s_dummy = reinterpret_cast<long long*>(smem + tables) + (size_t)waves_per_block * a.stage_cap;
+  long long* s_stage = reinterpret_cast<long long*>(smem + tables) + (size_t)wave * (a.stage_cap + kWave);
 
   for (uint32_t k = (uint32_t)lane; k < a.stage_cap; k += kWave) s_stage[k] = 0;
   if (kLdsTables) {
-    for (int i = (int)threadIdx.x; i < P; i += (int)blockDim.x) {
+    for (int i = (int)threadIdx.x; i < P1; i += (int)blockDim.x) {
       s_price[i] = (PriceT)a.price[i];
       s_hist[i] = 0u;
     }
     __syncthreads();
   }
+  const uint32_t lt_lo = lane < 32 ? ((1u << lane) - 1u) : 0xffffffffu;      // lanes below this one
+  const uint32_t lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
 
   const long long g = (long long)blockIdx.x * waves_per_block + wave;   // global wave index
   const long long t0 = g * a.tiles_per_wave;
@@ -314,10 +350,10 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
   if (t1 > a.n_tiles) t1 = a.n_tiles;
 
   if (t0 < t1) {
-    const long long n_full = a.n_lines / kTile;      // tiles [0, n_full) are complete
+    const long long n_full = a.n_lines / kTileL;     // tiles [0, n_full) are complete
     const long long tf = t1 < n_full ? t1 : n_full;  // this wave's complete tiles are [t0, tf)
     WaveRun o;
-    o.id = a.order_id[t0 * kTile];                   // the wave's run starts inside this order
+    o.id = a.order_id[t0 * kTileL];                  // the wave's run starts inside this order
     o.sum = 0;
     o.first_open = true;
     o.head_sum = 0;
@@ -326,41 +362,39 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
     const int head_id = o.id;
 
     if (t0 < tf) {
-      // software pipeline: the next tile's three 16-byte loads are in flight while this tile is
-      // processed.  The last iteration re-loads its own tile instead of branching around the load.
-      const int32_t* p_id = a.order_id + t0 * kTile + lane * kLinesPerLane;
-      const int32_t* p_pr = a.product_idx + t0 * kTile + lane * kLinesPerLane;
-      const int32_t* p_q = a.qty + t0 * kTile + lane * kLinesPerLane;
-      int4 cid = load_stream16(p_id);
-      int4 cpr = load_stream16(p_pr);
-      int4 cq = load_stream16(p_q);
-      for (long long t = t0; t < tf; ++t) {
-        const long long step = (t + 1 < tf) ? kTile : 0;
-        p_id += step; p_pr += step; p_q += step;
-        const int4 nid = load_stream16(p_id);
-        const int4 npr = load_stream16(p_pr);
-        const int4 nq = load_stream16(p_q);
-        const int ids[4] = {cid.x, cid.y, cid.z, cid.w};
-        const int prs[4] = {cpr.x, cpr.y, cpr.z, cpr.w};
-        const int qs[4] = {cq.x, cq.y, cq.z, cq.w};
-        lines_tile<PriceT, kLdsTables>(a, s_price, s_hist, s_stage, s_dummy, ids, prs, qs, lane, o);
-        cid = nid; cpr = npr; cq = nq;
+      // software pipeline: the next tile's loads are in flight while this tile is processed.  The
+      // last iteration re-loads its own tile instead of branching around the loads.
+      const long long last = tf - 1;
+      long long off = t0 * kTileL + lane * LPL;
+      int nid[LPL], npr[LPL], nq[LPL];
+      load_lines<LPL>(a.order_id + off, nid);
+      load_lines<LPL>(a.product_idx + off, npr);
+      load_lines<LPL>(a.qty + off, nq);
+      for (long long t = t0; t <= last; ++t) {
+        int ids[LPL], prs[LPL], qs[LPL];
+#pragma unroll
+        for (int i = 0; i < LPL; ++i) { ids[i] = nid[i]; prs[i] = npr[i]; qs[i] = nq[i]; }
+        off += (t < last) ? kTileL : 0;
+        load_lines<LPL>(a.order_id + off, nid);
+        load_lines<LPL>(a.product_idx + off, npr);
+        load_lines<LPL>(a.qty + off, nq);
+        lines_tile<PriceT, kLdsTables, LPL>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o);
       }
     }
     if (tf < t1) {
       // the data set's last, partial tile: lines past the end repeat the last order id, add nothing
-      const long long l0 = tf * kTile + (long long)lane * kLinesPerLane;
+      const long long l0 = tf * kTileL + (long long)lane * LPL;
       const int last_id = a.order_id[a.n_lines - 1];
-      int ids[4], prs[4], qs[4];
+      int ids[LPL], prs[LPL], qs[LPL];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < LPL; ++i) {
         const long long l = l0 + i;
         const bool in = l < a.n_lines;
         ids[i] = in ? a.order_id[l] : last_id;
         prs[i] = in ? a.product_idx[l] : -1;
         qs[i] = in ? a.qty[l] : 0;
       }
-      lines_tile<PriceT, kLdsTables>(a, s_price, s_hist, s_stage, s_dummy, ids, prs, qs, lane, o);
+      lines_tile<PriceT, kLdsTables, LPL>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o);
     }
     // orders closed since the last flush (everything below the order that is still open)
     stage_flush(a, s_stage, o, min(((uint32_t)o.id - (uint32_t)a.base) - o.buf_base, a.stage_cap), lane);
@@ -380,7 +414,7 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
   if (kLdsTables) {
     __syncthreads();
     uint32_t* slab = a.prod_slab + (size_t)blockIdx.x * a.p_pad;
-    for (int i = (int)threadIdx.x; i < P; i += (int)blockDim.x) slab[i] = s_hist[i];
+    for (int i = (int)threadIdx.x; i < a.n_products; i += (int)blockDim.x) slab[i] = s_hist[i];
   }
 }
 
