@@ -299,6 +299,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     f.prod_slab = ctx->d_prod_slab.p; f.n_slabs = lp.blocks; f.p_pad = ctx->p_pad; f.n_products = P;
     f.merge_products = lp.lds_tables ? 1 : 0;
     f.prod_carry = ctx->d_prod_carry.p; f.product_qty = d_pq;
+    f.ablate = env_int("ACMPC_FIX_ABLATE", 0);
     const size_t fix_lds = (size_t)kFixThreads * kFixStrip * 12;
     if ((rc = set_dyn_lds(ctx, k_fixup, fix_lds))) return rc;
     const int fix_blocks = 1 + (lp.lds_tables ? (P + kMergeProducts - 1) / kMergeProducts : 0);

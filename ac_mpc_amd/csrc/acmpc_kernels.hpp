@@ -436,6 +436,7 @@ struct FixArgs {
   int32_t merge_products;   // 1: blocks >= 1 merge the stock-delta slabs
   unsigned long long* prod_carry;
   int64_t* product_qty;
+  int32_t ablate;           // developer switch for timing experiments: 1 skip merge blocks, 2 skip block 0
 };
 
 __device__ __forceinline__ void block_fill_zero(int64_t* out, long long lo, long long hi, int n_orders) {
@@ -452,7 +453,7 @@ __global__ void __launch_bounds__(kFixThreads) k_fixup(FixArgs a) {
 
   if (blockIdx.x > 0) {
     // ---- stock-delta merge: 64 products per block, wave w sums slabs w, w+16, ...
-    if (!a.merge_products) return;
+    if (!a.merge_products || (a.ablate & 1)) return;
     unsigned long long* s_part = reinterpret_cast<unsigned long long*>(smem);   // [16][64]
     const int p = ((int)blockIdx.x - 1) * kMergeProducts + lane;
     unsigned long long acc = 0;
@@ -470,6 +471,7 @@ __global__ void __launch_bounds__(kFixThreads) k_fixup(FixArgs a) {
     return;
   }
 
+  if (a.ablate & 2) return;
   // ---- block 0: orders cut by wave boundaries.  Records are (order id, partial sum), two per
   // wave, in line order, hence sorted by id.  Every maximal run of equal ids is one order.
   long long* s_excl = reinterpret_cast<long long*>(smem);                       // [n_rec]
@@ -661,7 +663,9 @@ __global__ void __launch_bounds__(1024) k_customers(CustArgs a) {
   if (len < 0) len = 0;
 
   if (kLdsTables) {
-    for (int i = (int)threadIdx.x; i < len; i += (int)blockDim.x) s_tab[i] = 0u;
+    // span is a multiple of 4: clear whole 16-byte groups (cells past len are never read)
+    for (int i = (int)threadIdx.x * 4; i < a.span; i += (int)blockDim.x * 4)
+      *reinterpret_cast<uint4*>(s_tab + i) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
   }
   uint32_t st = 0;
@@ -672,7 +676,7 @@ __global__ void __launch_bounds__(1024) k_customers(CustArgs a) {
   const long long tf = t1 < n_full ? t1 : n_full;         // complete tiles of this stream: [t0, tf)
 
   long long t = t0 + wave;
-  if (t < tf) {
+  if (t < tf && !(a.ablate & 2)) {
     // Software pipeline over this wave's tiles (t, t + W, t + 2W, ...) with kCustDepth tiles in
     // flight: most of these loads are L2 hits shared with the sibling workgroups, and a CU needs
     // far more bytes in flight to stream from L2 than to stream its share of HBM.  Loads past the
@@ -726,8 +730,13 @@ __global__ void __launch_bounds__(1024) k_customers(CustArgs a) {
   if (st && r == 0) atomicOr(a.status, st);
   if (kLdsTables) {
     __syncthreads();
+    // lo and c_pad are multiples of 4, so the slab slice is 16-byte aligned; the few cells past len
+    // (inside the row's padding or the next range's start) are rewritten by their owner or unused
     uint32_t* slab = a.cust_slab + (size_t)s * a.c_pad + lo;
-    for (int i = (int)threadIdx.x; i < len; i += (int)blockDim.x) slab[i] = s_tab[i];
+    const int len4 = len & ~3;
+    for (int i = (int)threadIdx.x * 4; i < len4; i += (int)blockDim.x * 4)
+      *reinterpret_cast<uint4*>(slab + i) = *reinterpret_cast<const uint4*>(s_tab + i);
+    for (int i = len4 + (int)threadIdx.x; i < len; i += (int)blockDim.x) slab[i] = s_tab[i];
   }
 }
 

@@ -82,10 +82,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    # Rehearsal on a box with fewer GPUs than ranks (never used by the driver): ACMPC_BENCH_BACKEND=gloo
+    # puts every rank on ACMPC_BENCH_DEVICE and moves the one all-reduce to the CPU.
+    backend = os.environ.get("ACMPC_BENCH_BACKEND", "nccl")
+    if "ACMPC_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["ACMPC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     motor = MotorLote(local_rank)
     n_total = args.lines_per_gpu * world
@@ -100,7 +108,12 @@ def main():
     def step():
         motor.agregar_device(ds.order_id, ds.product_idx, ds.qty, ds.order_customer, ds.order_id_base, Cn, tot, pq, ct)
         if world > 1:
-            reparto.fusionar(merged)
+            if backend == "nccl":
+                reparto.fusionar(merged)
+            else:
+                host = merged.cpu()
+                reparto.fusionar(host)
+                merged.copy_(host)
 
     def fence():
         torch.cuda.synchronize()
@@ -118,7 +131,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert motor.estado() == 0

@@ -239,6 +239,8 @@ int main(int argc, char** argv) {
   {
     const long long m = n / 4;
     for (int R : {1, 2, 4}) { run_sib<1, false>(R, 256, 1024, a, out, m, sink); run_sib<4, false>(R, 256, 1024, a, out, m, sink); run_sib<4, true>(R, 256, 1024, a, out, m, sink); }
+    run_sib<4, false>(3, 240, 1024, a, out, m, sink);
+    run_sib<1, false>(3, 240, 1024, a, out, m, sink);
     run_sib<2, false>(4, 256, 512, a, out, m, sink);
     run_sib<4, false>(4, 512, 512, a, out, m, sink);
     run_sib<4, false>(8, 512, 512, a, out, m, sink);
