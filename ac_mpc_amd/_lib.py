@@ -1,7 +1,7 @@
 """ctypes binding of libacmpc.so (the C ABI declared in include/acmpc.h).
 
 There is no fallback: if the shared library is missing or fails to load, importing the engine
-raises.  Build it with ``python -m ac_mpc_amd.build`` (hipcc, gfx950).
+raises.  Build it with ``python build_native.py`` (hipcc, gfx950).
 """
 from __future__ import annotations
 
@@ -14,13 +14,14 @@ LIB_PATH = os.path.join(_HERE, "lib", "libacmpc.so")
 # Every symbol include/acmpc.h declares; tests check that the library exports all of them.
 EXPORTS = (
     "acmpc_init", "acmpc_destroy", "acmpc_last_error", "acmpc_version", "acmpc_set_products",
-    "acmpc_aggregate", "acmpc_aggregate_device", "acmpc_status", "acmpc_set_profiling",
+    "acmpc_aggregate", "acmpc_aggregate_device", "acmpc_status", "acmpc_set_option", "acmpc_set_profiling",
     "acmpc_last_kernel_ms", "acmpc_lines_geometry", "acmpc_synth_plan", "acmpc_synth_prices",
     "acmpc_synth_generate_device",
 )
 
 OK, E_INVALID, E_HIP, E_ALIGN, E_DATA, E_STATE, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
 ST_ORDER_RANGE, ST_ORDER_UNSORTED, ST_CUSTOMER_RANGE = 1, 2, 4
+OPT_LINE_ORDER, ORDER_GROUPED, ORDER_ANY = 1, 0, 1
 K_LINES, K_FIXUP, K_CUSTOMERS, K_CUSTMERGE, N_KERNELS = 0, 1, 2, 3, 4
 
 
@@ -64,7 +65,7 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built "
-            "(run `python -m ac_mpc_amd.build`). There is no CPU fallback.")
+            "(run `python build_native.py`). There is no CPU fallback.")
     _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, u32p = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_uint32)
@@ -84,6 +85,8 @@ def load() -> C.CDLL:
     lib.acmpc_aggregate_device.restype = C.c_int
     lib.acmpc_status.argtypes = [vp, vp, u32p]
     lib.acmpc_status.restype = C.c_int
+    lib.acmpc_set_option.argtypes = [vp, C.c_int, i64]
+    lib.acmpc_set_option.restype = C.c_int
     lib.acmpc_set_profiling.argtypes = [vp, C.c_int]
     lib.acmpc_set_profiling.restype = C.c_int
     lib.acmpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]

@@ -63,6 +63,7 @@ struct acmpc_ctx {
   int k1_lpl = 4;
   int k2_threads = 1024;
   int force_global_tables = 0;
+  int line_order = ACMPC_ORDER_GROUPED;
 
   // profiling
   bool profiling = false;
@@ -229,6 +230,18 @@ int launch_lines(acmpc_ctx* ctx, const LinesPlan& pl, const LinesArgs& a, hipStr
   return ACMPC_OK;
 }
 
+template <typename PriceT, bool kLds>
+int launch_lines_any(acmpc_ctx* ctx, const LinesPlan& pl, size_t lds_bytes, const LinesArgs& a, hipStream_t st) {
+  auto kern = k_lines_any<PriceT, kLds>;
+  if (lds_bytes) {
+    int rc = set_dyn_lds(ctx, kern, lds_bytes);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(pl.threads), lds_bytes, st, a);
+  HIPCHK(ctx, hipGetLastError());
+  return ACMPC_OK;
+}
+
 int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32_t* d_product_idx,
                           const int32_t* d_qty, int64_t n_lines, const int32_t* d_order_customer,
                           int64_t n_orders, int32_t base, int32_t n_customers, int64_t* d_tot,
@@ -257,6 +270,13 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
   // ---- order-line pass ------------------------------------------------------------------
   LinesPlan lp;
   plan_lines(ctx, n_lines, &lp);
+  const bool any_order = ctx->line_order == ACMPC_ORDER_ANY;
+  if (any_order && lp.lpl != 4) {            // the any-order kernel works on 256-line tiles
+    const int keep = ctx->k1_lpl;
+    ctx->k1_lpl = 4;
+    plan_lines(ctx, n_lines, &lp);
+    ctx->k1_lpl = keep;
+  }
   int rc;
   if (n_lines == 0) {
     if (n_orders > 0) HIPCHK(ctx, hipMemsetAsync(d_tot, 0, (size_t)n_orders * 8, st));
@@ -286,7 +306,14 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.rec_id = ctx->d_rec_id.p; a.rec_sum = ctx->d_rec_sum.p; a.status = ctx->d_status;
 
     ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
-    if (!lp.lds_tables) rc = launch_lines<int64_t, false, 4>(ctx, lp, a, st);
+    if (any_order) {
+      HIPCHK(ctx, hipMemsetAsync(d_tot, 0, (size_t)n_orders * 8, st));
+      const size_t tables = lp.lds_tables ? (size_t)ctx->p_pad * (lp.price32 ? 8 : 12) : 0;
+      if (!lp.lds_tables) rc = launch_lines_any<int64_t, false>(ctx, lp, tables, a, st);
+      else if (lp.price32) rc = launch_lines_any<int32_t, true>(ctx, lp, tables, a, st);
+      else rc = launch_lines_any<int64_t, true>(ctx, lp, tables, a, st);
+    }
+    else if (!lp.lds_tables) rc = launch_lines<int64_t, false, 4>(ctx, lp, a, st);
     else if (lp.price32 && lp.lpl == 8) rc = launch_lines<int32_t, true, 8>(ctx, lp, a, st);
     else if (lp.price32) rc = launch_lines<int32_t, true, 4>(ctx, lp, a, st);
     else rc = launch_lines<int64_t, true, 4>(ctx, lp, a, st);
@@ -298,6 +325,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     f.base = base; f.n_orders = (int32_t)n_orders; f.order_total = d_tot; f.status = ctx->d_status;
     f.prod_slab = ctx->d_prod_slab.p; f.n_slabs = lp.blocks; f.p_pad = ctx->p_pad; f.n_products = P;
     f.merge_products = lp.lds_tables ? 1 : 0;
+    f.fix_orders = any_order ? 0 : 1;
     f.prod_carry = ctx->d_prod_carry.p; f.product_qty = d_pq;
     f.ablate = env_int("ACMPC_FIX_ABLATE", 0);
     const size_t fix_lds = (size_t)kFixThreads * kFixStrip * 12;
@@ -537,6 +565,15 @@ ACMPC_API int acmpc_aggregate(acmpc_ctx* ctx, const int32_t* order_id, const int
   HIPCHK(ctx, hipMemcpyAsync(out_customer_total_cents, ctx->s_customer_total.p, (size_t)n_customers * 8, hipMemcpyDeviceToHost, st));
   uint32_t flags = 0;
   return acmpc_status(ctx, st, &flags);
+}
+
+ACMPC_API int acmpc_set_option(acmpc_ctx* ctx, int option, int64_t value) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_set_option: null context");
+  if (option == ACMPC_OPT_LINE_ORDER && (value == ACMPC_ORDER_GROUPED || value == ACMPC_ORDER_ANY)) {
+    ctx->line_order = (int)value;
+    return ACMPC_OK;
+  }
+  return fail(ctx, ACMPC_E_INVALID, "acmpc_set_option: unknown option %d or value %lld", option, (long long)value);
 }
 
 ACMPC_API int acmpc_set_profiling(acmpc_ctx* ctx, int enabled) {

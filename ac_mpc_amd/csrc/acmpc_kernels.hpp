@@ -419,6 +419,128 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_lines_any — the same sums when the `detalle` rows are NOT grouped by order (concurrent checkouts
+// interleave their inserts: process/confirmcompra.php:27,35-37 and the table has no key that would
+// order them, store.sql:192-194).  order_total must be zero on entry.  Runs of equal order ids are
+// still combined inside a tile (one 64-bit global atomic per run), so almost-grouped input costs about
+// one atomic per order; fully shuffled input costs one per line.
+// ---------------------------------------------------------------------------------------------
+template <typename PriceT, bool kLdsTables>
+__global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
+  constexpr int LPL = kLinesPerLane;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const int waves_per_block = (int)(blockDim.x >> 6);
+  const uint32_t P = (uint32_t)a.n_products;
+  PriceT* s_price = reinterpret_cast<PriceT*>(smem);
+  uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + (size_t)a.p_pad * sizeof(PriceT));
+  if (kLdsTables) {
+    for (int i = (int)threadIdx.x; i < (int)P + 1; i += (int)blockDim.x) {
+      s_price[i] = (PriceT)a.price[i];
+      s_hist[i] = 0u;
+    }
+    __syncthreads();
+  }
+  const uint32_t lt_lo = lane < 32 ? ((1u << lane) - 1u) : 0xffffffffu;
+  const uint32_t lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
+  unsigned long long* tot_cells = reinterpret_cast<unsigned long long*>(a.order_total);
+
+  const long long g = (long long)blockIdx.x * waves_per_block + wave;
+  const long long t0 = g * a.tiles_per_wave;
+  long long t1 = t0 + a.tiles_per_wave;
+  if (t1 > a.n_tiles) t1 = a.n_tiles;
+  uint32_t st = 0;
+  for (long long t = t0; t < t1; ++t) {
+    const long long l0 = t * kTile + (long long)lane * LPL;
+    int ids[LPL], prs[LPL], qs[LPL];
+    if (l0 + LPL <= a.n_lines) {
+      load_lines<LPL>(a.order_id + l0, ids);
+      load_lines<LPL>(a.product_idx + l0, prs);
+      load_lines<LPL>(a.qty + l0, qs);
+    } else {
+      // past the end: repeat the last real order id of the data set, unknown product, quantity 0
+      const int last_id = a.order_id[a.n_lines - 1];
+#pragma unroll
+      for (int i = 0; i < LPL; ++i) {
+        const bool in = l0 + i < a.n_lines;
+        ids[i] = in ? a.order_id[l0 + i] : last_id;
+        prs[i] = in ? a.product_idx[l0 + i] : -1;
+        qs[i] = in ? a.qty[l0 + i] : 0;
+      }
+    }
+    uint32_t pi[LPL];
+    long long v[LPL];
+    uint32_t qmax = 0;
+#pragma unroll
+    for (int i = 0; i < LPL; ++i) pi[i] = min((uint32_t)prs[i], P);
+#pragma unroll
+    for (int i = 0; i < LPL; ++i) {
+      if (kLdsTables) {
+        v[i] = (long long)s_price[pi[i]] * (long long)qs[i];
+        __hip_atomic_fetch_add(&s_hist[pi[i]], (uint32_t)qs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        qmax = max(qmax, (uint32_t)qs[i]);
+      } else {
+        v[i] = a.price[pi[i]] * (long long)qs[i];
+        if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qs[i]);
+      }
+    }
+    if (kLdsTables && qmax >= a.q_small) {
+#pragma unroll
+      for (int i = 0; i < LPL; ++i) {
+        if ((uint32_t)qs[i] >= a.q_small) {
+          __hip_atomic_fetch_add(&s_hist[pi[i]], 0u - (uint32_t)qs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qs[i]);
+        }
+      }
+    }
+    // runs of equal ids inside the tile (no carry between tiles: every tile settles its own runs)
+    const int first = __builtin_amdgcn_readfirstlane(ids[0]);
+    const int prev = wave_shift_up1(ids[LPL - 1], first);
+    int d[LPL];
+    d[0] = ids[0] - prev;
+#pragma unroll
+    for (int i = 1; i < LPL; ++i) d[i] = ids[i] - ids[i - 1];
+    int dor = d[0];
+    long long r = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < LPL; ++i) {
+      if (i) dor |= d[i];
+      r = d[i] ? 0ll : r;
+      r += v[i];
+      tot += v[i];
+    }
+    const long long incl = wave_inclusive_scan(tot);
+    const long long excl = incl - tot;
+    const unsigned long long headmask = __ballot(dor != 0);
+    const uint32_t below_lo = (uint32_t)headmask & lt_lo, below_hi = (uint32_t)(headmask >> 32) & lt_hi;
+    const bool any_below = (below_lo | below_hi) != 0u;
+    const int j = below_hi ? (63 - __clz(below_hi)) : (31 - __clz(below_lo | 1u));
+    const long long gj = __shfl(r - incl, j);
+    long long run = excl + (any_below ? gj : 0ll);
+    int pid = prev;
+    auto settle = [&](int oid, long long sum) {
+      const uint32_t idx = (uint32_t)oid - (uint32_t)a.base;
+      if (idx >= (uint32_t)a.n_orders) st |= kStOrderRange;
+      else if (sum != 0) atomicAdd(&tot_cells[idx], (unsigned long long)sum);
+    };
+#pragma unroll
+    for (int i = 0; i < LPL; ++i) {
+      if (ids[i] != pid) { settle(pid, run); run = 0; }
+      run += v[i];
+      pid = ids[i];
+    }
+    if (lane == kWave - 1) settle(pid, run);          // the tile's last run
+  }
+  if (st) atomicOr(a.status, st);
+  if (kLdsTables) {
+    __syncthreads();
+    uint32_t* slab = a.prod_slab + (size_t)blockIdx.x * a.p_pad;
+    for (int i = (int)threadIdx.x; i < a.n_products; i += (int)blockDim.x) slab[i] = s_hist[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_fixup
 // ---------------------------------------------------------------------------------------------
 struct FixArgs {
@@ -434,6 +556,7 @@ struct FixArgs {
   int32_t p_pad;
   int32_t n_products;
   int32_t merge_products;   // 1: blocks >= 1 merge the stock-delta slabs
+  int32_t fix_orders;       // 1: block 0 finishes the orders cut by wave boundaries (grouped input)
   unsigned long long* prod_carry;
   int64_t* product_qty;
   int32_t ablate;           // developer switch for timing experiments: 1 skip merge blocks, 2 skip block 0
@@ -471,7 +594,7 @@ __global__ void __launch_bounds__(kFixThreads) k_fixup(FixArgs a) {
     return;
   }
 
-  if (a.ablate & 2) return;
+  if ((a.ablate & 2) || !a.fix_orders) return;
   // ---- block 0: orders cut by wave boundaries.  Records are (order id, partial sum), two per
   // wave, in line order, hence sorted by id.  Every maximal run of equal ids is one order.
   long long* s_excl = reinterpret_cast<long long*>(smem);                       // [n_rec]

@@ -129,6 +129,14 @@ class MotorLote:
         self._check(self._lib.acmpc_status(self._ctx, stream, C.byref(flags)))
         return int(flags.value)
 
+    # -- options ------------------------------------------------------------------------------
+    def orden_lineas(self, cualquiera: bool) -> None:
+        """False (default): the `detalle` rows of an order are contiguous and order ids ascend, as
+        process/confirmcompra.php:35-37 writes them.  True: no promise (concurrent checkouts interleave
+        rows); same results through a slower atomic path."""
+        self._check(self._lib.acmpc_set_option(self._ctx, _lib.OPT_LINE_ORDER,
+                                               _lib.ORDER_ANY if cualquiera else _lib.ORDER_GROUPED))
+
     # -- kernel timing --------------------------------------------------------------------------
     def perfilar(self, activo: bool) -> None:
         self._check(self._lib.acmpc_set_profiling(self._ctx, 1 if activo else 0))

@@ -1,6 +1,7 @@
 """Build the native pieces in-tree: libacmpc.so (HIP, gfx950), the CPU oracle and the developer tool.
 
-Run as ``python -m ac_mpc_amd.build`` or through ``__graft_entry__.build()``.  hipcc cross-compiles
+Run as ``python build_native.py`` or through ``__graft_entry__.build()``.  It deliberately lives outside
+the ac_mpc_amd package: importing the package loads libacmpc.so, which is what this script creates.  hipcc cross-compiles
 for gfx950 without a GPU, so this works on a CPU-only machine.
 """
 from __future__ import annotations
@@ -9,7 +10,7 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "ac_mpc_amd")
 LIB = os.path.join(PKG, "lib", "libacmpc.so")
 ORACLE_DIR = os.path.join(ROOT, "oracle")

@@ -141,6 +141,22 @@ int acmpc_aggregate_device(acmpc_ctx* ctx,
 int acmpc_status(acmpc_ctx* ctx, void* hip_stream, uint32_t* flags);
 
 /*
+ * Options.  ACMPC_OPT_LINE_ORDER says what the caller promises about the `detalle` rows:
+ *   ACMPC_ORDER_GROUPED (default)  rows of one order contiguous, order ids non-decreasing — the
+ *                                  order in which process/confirmcompra.php:35-37 inserts them when
+ *                                  checkouts do not overlap; a violation is reported, not summed
+ *   ACMPC_ORDER_ANY                no promise: concurrent checkouts interleave their rows
+ *                                  (process/confirmcompra.php:27,35-37; `detalle` has no primary key,
+ *                                  store.sql:192-194).  Same results, through 64-bit global atomics
+ *                                  per run of equal ids: several times slower.
+ * No counterpart in the reference, which never reads `detalle` back.
+ */
+#define ACMPC_OPT_LINE_ORDER   1
+#define ACMPC_ORDER_GROUPED    0
+#define ACMPC_ORDER_ANY        1
+int acmpc_set_option(acmpc_ctx* ctx, int option, int64_t value);
+
+/*
  * Kernel timing.  With profiling enabled every acmpc_aggregate_device() call
  * brackets each of its kernels with HIP events on the call's stream;
  * acmpc_last_kernel_ms() waits for them and returns the milliseconds of the

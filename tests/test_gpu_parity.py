@@ -274,3 +274,55 @@ def test_full_size_100m_lines(motor, oracle, zipf):
     np.testing.assert_array_equal(tot.cpu().numpy(), etot)
     np.testing.assert_array_equal(pq.cpu().numpy(), epq)
     np.testing.assert_array_equal(ct.cpu().numpy(), ect)
+
+
+# ---- rows not grouped by order (concurrent checkouts interleave their detalle inserts) ------------
+
+def _check_any_order(motor, oracle, oid, pidx, qty, cust, base, c_n, price):
+    motor.orden_lineas(True)
+    try:
+        motor.cargar_productos(price)
+        tot, pq, ct = motor.agregar(oid, pidx, qty, cust, base, c_n)
+    finally:
+        motor.orden_lineas(False)
+    etot, epq, ect, flags = oracle.aggregate(oid, pidx, qty, cust, base, c_n, price)
+    assert flags & ~2 == 0                                  # the oracle only notes that ids are unsorted
+    np.testing.assert_array_equal(tot, etot)
+    np.testing.assert_array_equal(pq, epq)
+    np.testing.assert_array_equal(ct, ect)
+
+
+@pytest.mark.parametrize("n,p,c,mode", [(1000, 100, 50, "shuffle"), (300_003, 10_000, 100_000, "shuffle"),
+                                         (1_000_000, 10_000, 100_000, "interleave"), (2_000_000, 10_000, 100_000, "sorted"),
+                                         (700_001, 60_000, 3_000_000, "shuffle")])
+def test_any_line_order(motor, oracle, n, p, c, mode):
+    d = oracle.synth(n, p, c, zipf=1, qty_mode=1)
+    oid, pidx, qty = d["order_id"], d["product_idx"], d["qty"]
+    rng = np.random.default_rng(23)
+    if mode == "shuffle":
+        perm = rng.permutation(n)
+    elif mode == "interleave":
+        # two checkouts at a time insert alternately: swap neighbouring blocks of rows
+        perm = np.arange(n)
+        k = (n // 2) * 2
+        perm[:k] = perm[:k].reshape(-1, 2)[:, ::-1].reshape(-1)
+    else:
+        perm = np.arange(n)
+    _check_any_order(motor, oracle, oid[perm], pidx[perm], qty[perm], d["order_customer"], 5, c, oracle.synth_prices(p))
+
+
+def test_any_line_order_rough_values(motor, oracle):
+    v = np.load(os.path.join(GOLDEN, "synth_5k_rough.npz"))
+    rng = np.random.default_rng(29)
+    perm = rng.permutation(v["order_id"].size)
+    _check_any_order(motor, oracle, v["order_id"][perm], v["product_idx"][perm], v["qty"][perm], v["order_customer"],
+                     int(v["order_id_base"]), int(v["n_customers"]), v["price_cents"])
+
+
+def test_grouped_mode_still_rejects_shuffled_rows(motor, oracle):
+    d = oracle.synth(50_000, 100, 50)
+    perm = np.random.default_rng(31).permutation(50_000)
+    motor.cargar_productos(oracle.synth_prices(100))
+    with pytest.raises(ErrorLote) as e:
+        motor.agregar(d["order_id"][perm], d["product_idx"][perm], d["qty"][perm], d["order_customer"], 5, 50)
+    assert e.value.code == _lib.E_DATA
