@@ -1,6 +1,7 @@
 // acmpc.hip — host side of libacmpc.so: context, workspace, kernel launches, the C ABI of
 // include/acmpc.h.  Device code is in acmpc_kernels.hpp.  gfx950 only; no CPU backend.
 #include "acmpc_kernels.hpp"
+#include "acmpc_ingest.hpp"
 #include "../../include/acmpc.h"
 
 #include <algorithm>
@@ -56,6 +57,15 @@ struct acmpc_ctx {
   DevBuf<int64_t> s_order_total, s_product_qty, s_customer_total;
   DevBuf<int64_t> s_synth_off;
   DevBuf<unsigned long long> s_synth_cdf;
+
+  // text ingest: dictionary of the product codes, chunk row counts, scalars, staging
+  int32_t dict_products = 0;
+  uint32_t dict_mask = 0;
+  DevBuf<unsigned long long> d_dict_hash, d_codes;
+  DevBuf<int32_t> d_dict_idx;
+  DevBuf<long long> d_chunk_rows;
+  long long* d_ing_scalars = nullptr;      // [0] rows found, [1] malformed rows
+  DevBuf<unsigned char> s_text;
 
   // tuning (environment overrides, read once)
   int k1_threads = 1024;
@@ -472,6 +482,9 @@ ACMPC_API void acmpc_destroy(acmpc_ctx* ctx) {
   release(ctx->s_order_id); release(ctx->s_product_idx); release(ctx->s_qty); release(ctx->s_order_customer);
   release(ctx->s_order_total); release(ctx->s_product_qty); release(ctx->s_customer_total);
   release(ctx->s_synth_off); release(ctx->s_synth_cdf);
+  release(ctx->d_dict_hash); release(ctx->d_codes); release(ctx->d_dict_idx); release(ctx->d_chunk_rows);
+  release(ctx->s_text);
+  if (ctx->d_ing_scalars) (void)hipFree(ctx->d_ing_scalars);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   for (int i = 0; i <= ACMPC_N_KERNELS; ++i)
     if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -519,10 +532,12 @@ ACMPC_API int acmpc_status(acmpc_ctx* ctx, void* hip_stream, uint32_t* flags) {
   HIPCHK(ctx, hipStreamSynchronize(st));
   if (flags) *flags = f;
   if (f)
-    return fail(ctx, ACMPC_E_DATA, "data contract broken:%s%s%s",
+    return fail(ctx, ACMPC_E_DATA, "data contract broken:%s%s%s%s%s",
                 (f & ACMPC_ST_ORDER_RANGE) ? " order_id outside [base, base+M);" : "",
                 (f & ACMPC_ST_ORDER_UNSORTED) ? " order_id not non-decreasing;" : "",
-                (f & ACMPC_ST_CUSTOMER_RANGE) ? " order_customer outside [0, C);" : "");
+                (f & ACMPC_ST_CUSTOMER_RANGE) ? " order_customer outside [0, C);" : "",
+                (f & ACMPC_ST_INGEST_MALFORMED) ? " malformed detalle row in the text;" : "",
+                (f & ACMPC_ST_INGEST_CAPACITY) ? " more detalle rows than capacity_rows;" : "");
   return ACMPC_OK;
 }
 
@@ -666,4 +681,122 @@ ACMPC_API int acmpc_synth_generate_device(acmpc_ctx* ctx, const acmpc_synth_cfg*
   hipLaunchKernelGGL(k_synth, dim3(blocks), dim3(kSynthOrdersPerBlock), 0, st, a);
   HIPCHK(ctx, hipGetLastError());
   return ACMPC_OK;
+}
+
+// ---- text ingest -------------------------------------------------------------------------
+
+ACMPC_API int acmpc_set_product_codes(acmpc_ctx* ctx, const char* codes32, int32_t n_products) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_set_product_codes: null context");
+  if (!codes32 || n_products <= 0) return fail(ctx, ACMPC_E_INVALID, "acmpc_set_product_codes: empty code list");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  uint32_t size = 16;
+  while (size < 2u * (uint32_t)n_products + 2u) size <<= 1;
+  std::vector<unsigned long long> hash(size, 0ull), codes((size_t)n_products * 4, 0ull);
+  std::vector<int32_t> idx(size, -1);
+  for (int32_t i = 0; i < n_products; ++i) {
+    const char* c = codes32 + (size_t)i * 32;
+    size_t len = 0;
+    while (len < 32 && c[len]) ++len;
+    if (len > 30) return fail(ctx, ACMPC_E_INVALID, "product code %d is longer than 30 bytes (varchar(30), store.sql:110)", i);
+    unsigned long long h = 1469598103934665603ull;
+    for (size_t k = 0; k < len; ++k) {
+      const unsigned long long b = (unsigned char)c[k];
+      h = (h ^ b) * 1099511628211ull;
+      codes[(size_t)i * 4 + (k >> 3)] |= b << (8 * (k & 7));
+    }
+    uint32_t s = (uint32_t)h & (size - 1);
+    while (idx[s] >= 0) {
+      if (hash[s] == h && memcmp(&codes[(size_t)idx[s] * 4], &codes[(size_t)i * 4], 32) == 0)
+        return fail(ctx, ACMPC_E_INVALID, "product codes %d and %d are equal (CodigoProd is a primary key, store.sql:200)", idx[s], i);
+      s = (s + 1) & (size - 1);
+    }
+    idx[s] = i;
+    hash[s] = h;
+  }
+  int rc;
+  if ((rc = ensure(ctx, ctx->d_dict_hash, size))) return rc;
+  if ((rc = ensure(ctx, ctx->d_dict_idx, size))) return rc;
+  if ((rc = ensure(ctx, ctx->d_codes, codes.size()))) return rc;
+  HIPCHK(ctx, hipMemcpy(ctx->d_dict_hash.p, hash.data(), (size_t)size * 8, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ctx->d_dict_idx.p, idx.data(), (size_t)size * 4, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ctx->d_codes.p, codes.data(), codes.size() * 8, hipMemcpyHostToDevice));
+  if (!ctx->d_ing_scalars) HIPCHK(ctx, hipMalloc((void**)&ctx->d_ing_scalars, 2 * sizeof(long long)));
+  ctx->dict_mask = size - 1;
+  ctx->dict_products = n_products;
+  return ACMPC_OK;
+}
+
+ACMPC_API int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, int64_t n_bytes, int32_t* d_order_id,
+                                          int32_t* d_product_idx, int32_t* d_qty, int64_t capacity_rows,
+                                          int64_t* d_n_rows, void* hip_stream) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_ingest_detalle_device: null context");
+  if (ctx->dict_products <= 0) return fail(ctx, ACMPC_E_STATE, "acmpc_set_product_codes has not been called");
+  if (n_bytes < 0 || capacity_rows < 0 || !d_n_rows) return fail(ctx, ACMPC_E_INVALID, "bad size or null row counter");
+  if (n_bytes > 0 && !d_text) return fail(ctx, ACMPC_E_INVALID, "null text pointer");
+  if (capacity_rows > 0 && (!d_order_id || !d_product_idx || !d_qty)) return fail(ctx, ACMPC_E_INVALID, "null column pointer");
+  if (!aligned16(d_text)) return fail(ctx, ACMPC_E_ALIGN, "device text must be 16-byte aligned");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  IngestArgs a;
+  a.text = reinterpret_cast<const unsigned char*>(d_text);
+  a.n_bytes = n_bytes;
+  a.n_chunks = (n_bytes + kIngChunk - 1) / kIngChunk;
+  int rc;
+  if ((rc = ensure(ctx, ctx->d_chunk_rows, (size_t)a.n_chunks + 1))) return rc;
+  a.chunk_rows = ctx->d_chunk_rows.p;
+  a.dict_hash = ctx->d_dict_hash.p; a.dict_idx = ctx->d_dict_idx.p; a.dict_mask = ctx->dict_mask;
+  a.codes = ctx->d_codes.p;
+  a.order_id = d_order_id; a.product_idx = d_product_idx; a.qty = d_qty; a.capacity = capacity_rows;
+  a.n_rows = reinterpret_cast<long long*>(d_n_rows);
+  a.n_malformed = reinterpret_cast<unsigned long long*>(ctx->d_ing_scalars + 1);
+  a.status = ctx->d_status;
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_ing_scalars, 0, 2 * sizeof(long long), st));
+  if (a.n_chunks == 0) {
+    HIPCHK(ctx, hipMemsetAsync(d_n_rows, 0, sizeof(int64_t), st));
+    return ACMPC_OK;
+  }
+  const int blocks = (int)std::min<int64_t>(a.n_chunks, (int64_t)ctx->n_cu * 8);
+  hipLaunchKernelGGL(k_ingest_count, dim3(blocks), dim3(kIngThreads), 0, st, a);
+  HIPCHK(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_ingest_scan, dim3(1), dim3(1024), 0, st, a);
+  HIPCHK(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_ingest_parse, dim3(blocks), dim3(kIngThreads), 0, st, a);
+  HIPCHK(ctx, hipGetLastError());
+  return ACMPC_OK;
+}
+
+ACMPC_API int acmpc_ingest_detalle(acmpc_ctx* ctx, const char* text, int64_t n_bytes, int32_t* order_id,
+                                   int32_t* product_idx, int32_t* qty, int64_t capacity_rows, int64_t* n_rows,
+                                   int64_t* n_malformed) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_ingest_detalle: null context");
+  if (ctx->dict_products <= 0) return fail(ctx, ACMPC_E_STATE, "acmpc_set_product_codes has not been called");
+  if (n_bytes < 0 || capacity_rows < 0 || !n_rows || (n_bytes > 0 && !text))
+    return fail(ctx, ACMPC_E_INVALID, "acmpc_ingest_detalle: bad argument");
+  if (capacity_rows > 0 && (!order_id || !product_idx || !qty)) return fail(ctx, ACMPC_E_INVALID, "null column pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->s_text, (size_t)n_bytes + 16))) return rc;
+  if ((rc = ensure(ctx, ctx->s_order_id, (size_t)capacity_rows))) return rc;
+  if ((rc = ensure(ctx, ctx->s_product_idx, (size_t)capacity_rows))) return rc;
+  if ((rc = ensure(ctx, ctx->s_qty, (size_t)capacity_rows))) return rc;
+  hipStream_t st = nullptr;
+  if (n_bytes > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->s_text.p, text, (size_t)n_bytes, hipMemcpyHostToDevice, st));
+  rc = acmpc_ingest_detalle_device(ctx, reinterpret_cast<const char*>(ctx->s_text.p), n_bytes, ctx->s_order_id.p,
+                                   ctx->s_product_idx.p, ctx->s_qty.p, capacity_rows,
+                                   reinterpret_cast<int64_t*>(ctx->d_ing_scalars), st);
+  if (rc) return rc;
+  long long scal[2] = {0, 0};
+  HIPCHK(ctx, hipMemcpyAsync(scal, ctx->d_ing_scalars, sizeof(scal), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  *n_rows = scal[0];
+  if (n_malformed) *n_malformed = scal[1];
+  const int64_t got = std::min<int64_t>(scal[0], capacity_rows);
+  if (got > 0) {
+    HIPCHK(ctx, hipMemcpy(order_id, ctx->s_order_id.p, (size_t)got * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(product_idx, ctx->s_product_idx.p, (size_t)got * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(qty, ctx->s_qty.p, (size_t)got * 4, hipMemcpyDeviceToHost));
+  }
+  uint32_t flags = 0;
+  return acmpc_status(ctx, st, &flags);
 }

@@ -35,7 +35,7 @@ def _run(cmd, cwd=None):
 
 def build_library(force: bool = False) -> str:
     srcs = [os.path.join(PKG, "csrc", "acmpc.hip"), os.path.join(PKG, "csrc", "acmpc_kernels.hpp"),
-            os.path.join(ROOT, "include", "acmpc.h")]
+            os.path.join(PKG, "csrc", "acmpc_ingest.hpp"), os.path.join(ROOT, "include", "acmpc.h")]
     if force or not _newer(LIB, srcs):
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
         _run([HIPCC, *HIP_FLAGS, "-shared", "-o", LIB, srcs[0]])
@@ -43,7 +43,8 @@ def build_library(force: bool = False) -> str:
 
 
 def build_oracle(force: bool = False) -> str:
-    if force or not _newer(ORACLE_LIB, [os.path.join(ORACLE_DIR, "aggregate_oracle.c")]):
+    if force or not _newer(ORACLE_LIB, [os.path.join(ORACLE_DIR, "aggregate_oracle.c"),
+                                        os.path.join(ORACLE_DIR, "ingest_oracle.c")]):
         _run(["make", "-C", ORACLE_DIR, "-B", "liboracle.so"])
     return ORACLE_LIB
 

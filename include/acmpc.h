@@ -53,6 +53,8 @@ typedef struct acmpc_ctx acmpc_ctx;
 #define ACMPC_ST_ORDER_RANGE     1u /* some order_id outside [base, base+M)             */
 #define ACMPC_ST_ORDER_UNSORTED  2u /* order_id column is not non-decreasing            */
 #define ACMPC_ST_CUSTOMER_RANGE  4u /* some order_customer outside [0, C)               */
+#define ACMPC_ST_INGEST_MALFORMED 8u /* acmpc_ingest_*: a data row did not match the grammar */
+#define ACMPC_ST_INGEST_CAPACITY 16u /* acmpc_ingest_*: more data rows than capacity_rows    */
 
 /* Kernel slots of acmpc_last_kernel_ms(). */
 #define ACMPC_K_LINES      0   /* order-line pass: totals, stock deltas               */
@@ -167,6 +169,48 @@ int acmpc_last_kernel_ms(acmpc_ctx* ctx, float* ms);
 
 /* Launch geometry of the order-line pass: workgroups and waves per workgroup. */
 int acmpc_lines_geometry(acmpc_ctx* ctx, int32_t* n_workgroups, int32_t* waves_per_workgroup);
+
+/* ------------------------------------------------------------------------
+ * Text ingest: `detalle` rows as SQL-dump / CSV text -> the three int32 columns.
+ *
+ * Accepted text (the shapes the reference itself writes):
+ *   - the statement process/confirmcompra.php:36 sends through library/consulSQL.php:29-30:
+ *       insert into detalle (NumPedido, CodigoProd, CantidadProductos) VALUES('5', '1', '1')
+ *   - the phpMyAdmin dump style of store.sql:88-89,125-128: an "INSERT INTO `t` (...) VALUES" header
+ *     line followed by one "(5, '1', 1)," row per line, the last ending in ";"
+ *   - plain comma- or tab-separated rows, one per line
+ * Grammar.  A row starts at offset 0 or after '\n'.  It is a DATA row iff its first byte is a
+ * digit, '-' followed by a digit, '(' or a quote; any other line (INSERT header, "--" comment,
+ * blank) is skipped.
+ *   row  := ['('] sp int sp sep sp code sp sep sp int sp [')'] [','|';'] ['\r'] ('\n' | end of text)
+ *   int  := [q] ['-'] digit{1,10} [q]        must fit int32; q is ' or " and must match
+ *   code := q bytes q  (no q, no '\n' inside; a doubled q is not accepted)
+ *         | bytes up to one of , \t space \r \n )           0..30 bytes (varchar(30), store.sql:99)
+ *   sep  := ',' | '\t'      sp := ' '*      a row is at most 120 bytes before its '\n'
+ * A data row that does not match yields (0, -1, 0), is counted, and raises
+ * ACMPC_ST_INGEST_MALFORMED.  CodigoProd is matched byte for byte against the code list; an
+ * unknown code becomes product_idx -1 (it adds nothing: process/carrito.php:13-14).
+ * Rows keep their order in the text.  VALUES rows that share a line with the INSERT header, and
+ * several rows on one line, are not accepted (phpMyAdmin and mysqldump --skip-extended-insert
+ * write one row per line).
+ * ---------------------------------------------------------------------- */
+
+/* Product code list: n_products entries of 32 bytes each, NUL padded, codes of at most 30 bytes,
+ * in the same order as the price table of acmpc_set_products.  Host pointer. */
+int acmpc_set_product_codes(acmpc_ctx* ctx, const char* codes32, int32_t n_products);
+
+/* Parse n_bytes of DEVICE text (16-byte aligned) into DEVICE columns of capacity_rows entries.
+ * *d_n_rows (device int64) receives the number of data rows found (rows beyond capacity_rows are
+ * counted but not stored, and raise ACMPC_ST_INGEST_CAPACITY).  Enqueued on hip_stream. */
+int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, int64_t n_bytes,
+                                int32_t* d_order_id, int32_t* d_product_idx, int32_t* d_qty,
+                                int64_t capacity_rows, int64_t* d_n_rows, void* hip_stream);
+
+/* Same from HOST text into HOST columns; waits, and returns ACMPC_E_DATA if a row was malformed
+ * or capacity_rows was too small.  n_malformed may be NULL. */
+int acmpc_ingest_detalle(acmpc_ctx* ctx, const char* text, int64_t n_bytes,
+                         int32_t* order_id, int32_t* product_idx, int32_t* qty,
+                         int64_t capacity_rows, int64_t* n_rows, int64_t* n_malformed);
 
 /* ------------------------------------------------------------------------
  * Synthetic store.sql-schema data, integer-only and reproducible bit for bit

@@ -30,6 +30,8 @@ class Oracle:
         lib.oracle_synth_count_lines.restype = i64
         lib.oracle_synth_fill.argtypes = [i64, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp]
         lib.oracle_synth_fill.restype = None
+        lib.oracle_ingest_detalle.argtypes = [vp, i64, vp, i32, vp, vp, vp, i64, C.POINTER(i64)]
+        lib.oracle_ingest_detalle.restype = i64
         self.lib = lib
 
     def aggregate(self, order_id, product_idx, qty, order_customer, order_id_base, n_customers, price_cents):
@@ -69,3 +71,18 @@ class Oracle:
                                    cust.ctypes.data)
         return dict(order_id=oid, product_idx=pidx, qty=qty, order_customer=cust, n_orders_total=m_total,
                     line_lo=int(line_lo.value), order_id_base=order_id_base + order_lo)
+
+    def ingest(self, text: bytes, codes, capacity=None):
+        """Parse `detalle` text with the C oracle; returns (order_id, product_idx, qty, n_rows, n_malformed)."""
+        from ac_mpc_amd.ingesta import empaquetar_codigos
+        packed = empaquetar_codigos(codes)
+        if capacity is None:
+            capacity = text.count(b"\n") + 1
+        oid = np.empty(capacity, np.int32)
+        pidx = np.empty(capacity, np.int32)
+        qty = np.empty(capacity, np.int32)
+        bad = C.c_int64(0)
+        n = int(self.lib.oracle_ingest_detalle(text, len(text), packed.ctypes.data, len(codes), oid.ctypes.data,
+                                               pidx.ctypes.data, qty.ctypes.data, capacity, C.byref(bad)))
+        k = min(n, capacity)
+        return oid[:k], pidx[:k], qty[:k], n, int(bad.value)

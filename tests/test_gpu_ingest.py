@@ -1,0 +1,135 @@
+"""Parity of the device text ingest (through the C ABI) with the C oracle: identical columns, row for row."""
+import os
+
+import numpy as np
+import pytest
+
+from ac_mpc_amd import ErrorLote, _lib, ingesta
+from tests import ingest_cases as ic
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _same(motor, oracle, text, codes, expect_bad=0):
+    ingesta.cargar_codigos(motor, codes)
+    eoid, epidx, eqty, n, bad = oracle.ingest(text, codes)
+    assert bad == expect_bad
+    if bad:
+        with pytest.raises(ErrorLote) as e:
+            ingesta.leer_detalle(motor, text)
+        assert e.value.code == _lib.E_DATA and "malformed" in e.value.detail
+        return
+    oid, pidx, qty = ingesta.leer_detalle(motor, text)
+    assert oid.size == n
+    np.testing.assert_array_equal(oid, eoid)
+    np.testing.assert_array_equal(pidx, epidx)
+    np.testing.assert_array_equal(qty, eqty)
+
+
+def test_committed_dumps(motor, oracle):
+    v = np.load(os.path.join(GOLDEN, "synth_1k_zipf.npz"))
+    codes = [ic.code_of(p) for p in range(v["price_cents"].size)]
+    for name in ("detalle_dump.sql", "detalle_insert_stmt.sql"):
+        _same(motor, oracle, open(os.path.join(GOLDEN, name), "rb").read(), codes)
+    oid, pidx, qty = ingesta.leer_detalle(motor, open(os.path.join(GOLDEN, "detalle_dump.sql"), "rb").read())
+    np.testing.assert_array_equal(oid, v["order_id"])
+    np.testing.assert_array_equal(pidx, v["product_idx"])
+    np.testing.assert_array_equal(qty, v["qty"])
+
+
+def test_edge_rows_on_device_match_hand_expectations(motor):
+    """Malformed rows are reported; the stored columns still match the expectations row for row."""
+    import ctypes as C
+    ingesta.cargar_codigos(motor, ic.EDGE_CODES)
+    cap = len(ic.EDGE_EXPECT)
+    oid, pidx, qty = (np.empty(cap, np.int32) for _ in range(3))
+    n, bad = C.c_int64(0), C.c_int64(0)
+    rc = motor._lib.acmpc_ingest_detalle(motor._ctx, ic.EDGE_TEXT, len(ic.EDGE_TEXT), oid.ctypes.data, pidx.ctypes.data,
+                                         qty.ctypes.data, cap, C.byref(n), C.byref(bad))
+    assert rc == _lib.E_DATA and (n.value, bad.value) == (cap, ic.EDGE_BAD)
+    assert list(zip(oid.tolist(), pidx.tolist(), qty.tolist())) == ic.EDGE_EXPECT
+
+
+@pytest.mark.parametrize("style", ["dump", "csv", "tsv_crlf", "quoted"])
+@pytest.mark.parametrize("n", [1, 63, 5000, 400_003])
+def test_styles_and_sizes(motor, oracle, style, n):
+    d = oracle.synth(n, 10_000, 50, zipf=1, qty_mode=1)
+    pidx = d["product_idx"].copy()
+    pidx[::97] = -1
+    codes = [ic.code_of(p) for p in range(10_000)]
+    text = ic.render(d["order_id"].tolist(), pidx.tolist(), d["qty"].tolist(), style)
+    _same(motor, oracle, text, codes)
+
+
+def test_empty_and_header_only_text(motor, oracle):
+    _same(motor, oracle, b"", ["1"])
+    _same(motor, oracle, b"-- nothing here\nINSERT INTO `detalle` (`NumPedido`) VALUES\n\n", ["1"])
+
+
+def test_fuzzed_text_row_for_row(motor, oracle):
+    """Random corrupted lines: the device must classify and parse every line exactly like the oracle."""
+    import ctypes as C
+    rng = np.random.default_rng(43)
+    alphabet = list(b"0123456789 ,'\"()-;\t\rabSKU-x")
+    codes = ["1", "2", "3", "ab", "SKU-1", "a b", "abcdefghijklmnopqrstuvwxyz0123"]
+    lines = []
+    for i in range(60_000):
+        r = rng.random()
+        if r < 0.6:
+            a, q = int(rng.integers(-50, 2**31)), int(rng.integers(-3, 99))
+            c = codes[int(rng.integers(0, len(codes)))] if rng.random() < 0.8 else "zz"
+            ln = rng.choice([f"({a}, '{c}', {q}),", f"{a},{c},{q}", f"'{a}'\t\"{c}\"\t'{q}'\r", f"( {a} ,'{c}' , {q} );"]).encode("latin-1")
+            if rng.random() < 0.3:
+                k = int(rng.integers(0, len(ln)))
+                ln = ln[:k] + bytes([alphabet[int(rng.integers(0, len(alphabet)))]]) + ln[k + 1:]
+        elif r < 0.95:
+            ln = bytes(alphabet[int(j)] for j in rng.integers(0, len(alphabet), int(rng.integers(0, 60))))
+        else:
+            ln = b"(1, '" + b"x" * int(rng.integers(20, 200)) + b"', 1),"       # long rows, some beyond 120 bytes
+        lines.append(ln.replace(b"\n", b" "))
+    text = b"\n".join(lines)
+    ingesta.cargar_codigos(motor, codes)
+    eoid, epidx, eqty, n, bad = oracle.ingest(text, codes)
+    oid, pidx, qty = (np.empty(n, np.int32) for _ in range(3))
+    gn, gbad = C.c_int64(0), C.c_int64(0)
+    rc = motor._lib.acmpc_ingest_detalle(motor._ctx, text, len(text), oid.ctypes.data, pidx.ctypes.data, qty.ctypes.data,
+                                         n, C.byref(gn), C.byref(gbad))
+    assert rc == _lib.E_DATA and (gn.value, gbad.value) == (n, bad) and bad > 1000
+    np.testing.assert_array_equal(oid, eoid)
+    np.testing.assert_array_equal(pidx, epidx)
+    np.testing.assert_array_equal(qty, eqty)
+
+
+def test_capacity_too_small_is_reported(motor):
+    ingesta.cargar_codigos(motor, ["1"])
+    with pytest.raises(ErrorLote) as e:
+        ingesta.leer_detalle(motor, b"1,1,1\n2,1,1\n3,1,1\n", capacidad=2)
+    assert e.value.code == _lib.E_DATA and "capacity" in e.value.detail
+
+
+def test_ingest_then_aggregate_equals_oracle(motor, oracle):
+    """Text -> columns -> totals, all on the device, against oracle(parse) -> oracle(aggregate)."""
+    import torch
+    n, p, c = 1_000_003, 10_000, 100_000
+    d = oracle.synth(n, p, c, zipf=1, qty_mode=1)
+    codes = [ic.code_of(i) for i in range(p)]
+    text = ic.render(d["order_id"].tolist(), d["product_idx"].tolist(), d["qty"].tolist(), "dump")
+    ingesta.cargar_codigos(motor, codes)
+    price = oracle.synth_prices(p)
+    motor.cargar_productos(price)
+    dev = torch.device("cuda", motor.device)
+    t = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
+    oid, pidx, qty = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3))
+    nrows = torch.zeros(1, dtype=torch.int64, device=dev)
+    ingesta.leer_detalle_device(motor, t, oid, pidx, qty, nrows)
+    cust = torch.from_numpy(d["order_customer"]).to(dev)
+    tot = torch.empty(cust.numel(), dtype=torch.int64, device=dev)
+    pq = torch.empty(p, dtype=torch.int64, device=dev)
+    ct = torch.empty(c, dtype=torch.int64, device=dev)
+    motor.agregar_device(oid, pidx, qty, cust, 5, c, tot, pq, ct)
+    assert motor.estado() == 0 and int(nrows.item()) == n
+    etot, epq, ect, _ = oracle.aggregate(d["order_id"], d["product_idx"], d["qty"], d["order_customer"], 5, c, price)
+    np.testing.assert_array_equal(tot.cpu().numpy(), etot)
+    np.testing.assert_array_equal(pq.cpu().numpy(), epq)
+    np.testing.assert_array_equal(ct.cpu().numpy(), ect)
