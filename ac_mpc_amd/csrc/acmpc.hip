@@ -699,12 +699,11 @@ ACMPC_API int acmpc_set_product_codes(acmpc_ctx* ctx, const char* codes32, int32
     size_t len = 0;
     while (len < 32 && c[len]) ++len;
     if (len > 30) return fail(ctx, ACMPC_E_INVALID, "product code %d is longer than 30 bytes (varchar(30), store.sql:110)", i);
-    unsigned long long h = 1469598103934665603ull;
-    for (size_t k = 0; k < len; ++k) {
-      const unsigned long long b = (unsigned char)c[k];
-      h = (h ^ b) * 1099511628211ull;
-      codes[(size_t)i * 4 + (k >> 3)] |= b << (8 * (k & 7));
-    }
+    for (size_t k = 0; k < len; ++k)
+      codes[(size_t)i * 4 + (k >> 3)] |= (unsigned long long)(unsigned char)c[k] << (8 * (k & 7));
+    const unsigned long long kw[4] = {codes[(size_t)i * 4], codes[(size_t)i * 4 + 1], codes[(size_t)i * 4 + 2],
+                                      codes[(size_t)i * 4 + 3]};
+    const unsigned long long h = ing_code_hash(kw);
     uint32_t s = (uint32_t)h & (size - 1);
     while (idx[s] >= 0) {
       if (hash[s] == h && memcmp(&codes[(size_t)idx[s] * 4], &codes[(size_t)i * 4], 32) == 0)

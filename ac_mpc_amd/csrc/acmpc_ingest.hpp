@@ -84,6 +84,22 @@ __device__ __forceinline__ void ing_row_starts(const uint32_t (&w)[16], uint32_t
   }
 }
 
+// Bit k set: a line starts at byte k of the thread's 64 bytes (byte k-1 is '\n', or the text starts
+// there).  Lines are not classified here.
+__device__ __forceinline__ unsigned long long ing_line_start_mask(const uint32_t (&w)[16], uint32_t prev) {
+  unsigned long long mask = 0;
+  uint32_t carry = prev == '\n' ? 0x80u : 0u;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t nl = ing_newlines(w[j]);
+    const uint32_t st = (nl << 8) | carry;
+    carry = nl >> 24;
+    const uint32_t nib = ((st >> 7) & 1u) | ((st >> 14) & 2u) | ((st >> 21) & 4u) | ((st >> 28) & 8u);
+    mask |= (unsigned long long)nib << (4 * j);
+  }
+  return mask;
+}
+
 // Load the thread's 64 bytes (zero past the end of the text) and its neighbours.
 __device__ __forceinline__ void ing_load64(const unsigned char* text, int64_t n_bytes, int64_t base, uint32_t (&w)[16],
                                            uint32_t& prev, uint32_t& next2) {
@@ -160,12 +176,21 @@ __global__ void __launch_bounds__(1024) k_ingest_scan(IngestArgs a) {
   }
 }
 
-// Parser state over the LDS copy of the text: s[p] for p in [0, lim) is valid text, s[lim] reads as '\n'.
+// Hash of a product code given as its 32 NUL-padded bytes in four little-endian 64-bit words.
+__host__ __device__ __forceinline__ unsigned long long ing_code_hash(const unsigned long long (&k)[4]) {
+  unsigned long long h = k[0] * 0x9E3779B97F4A7C15ull;
+  h = (h ^ (h >> 29) ^ k[1]) * 0xBF58476D1CE4E5B9ull;
+  h = (h ^ (h >> 32) ^ k[2]) * 0x94D049BB133111EBull;
+  h = (h ^ (h >> 29) ^ k[3]) * 0x9E3779B97F4A7C15ull;
+  return h ^ (h >> 31);
+}
+
+// Parser state over the LDS copy of the text.  The staging code writes a '\n' right after the last
+// staged byte, and the parser never moves past a '\n', so no bounds check is needed per byte.
 struct IngCursor {
   const unsigned char* s;
   int p;
-  int lim;
-  __device__ __forceinline__ uint32_t peek() const { return p < lim ? (uint32_t)s[p] : (uint32_t)'\n'; }
+  __device__ __forceinline__ uint32_t peek() const { return (uint32_t)s[p]; }
 };
 
 __device__ __forceinline__ void ing_skip_sp(IngCursor& c) { while (c.peek() == ' ') ++c.p; }
@@ -209,12 +234,10 @@ __device__ __forceinline__ bool ing_row(IngCursor& c, const IngestArgs& a, int32
   ing_skip_sp(c);
   // product code: up to 30 bytes, packed into four 64-bit words (NUL padded) and hashed (FNV-1a)
   unsigned long long k[4] = {0, 0, 0, 0};
-  unsigned long long h = 1469598103934665603ull;
   int len = 0;
   uint32_t ch = c.peek();
   auto take = [&](uint32_t b) {
     if (len < 32) k[len >> 3] |= (unsigned long long)b << (8 * (len & 7));
-    h = (h ^ b) * 1099511628211ull;
     ++len;
   };
   if (ch == '\'' || ch == '"') {
@@ -239,8 +262,9 @@ __device__ __forceinline__ bool ing_row(IngCursor& c, const IngestArgs& a, int32
   if (c.peek() == '\r') ++c.p;
   if (c.peek() != '\n') return false;
   if (c.p - start > kIngMaxRow) return false;
-  // dictionary lookup: same hash, then the 32 code bytes must be identical
+  // dictionary lookup: hash of the four packed words, then the 32 code bytes must be identical
   pidx = -1;
+  const unsigned long long h = ing_code_hash(k);
   uint32_t slot = (uint32_t)h & a.dict_mask;
   for (;;) {
     const int32_t cand = a.dict_idx[slot];
@@ -254,7 +278,7 @@ __device__ __forceinline__ bool ing_row(IngCursor& c, const IngestArgs& a, int32
   return true;
 }
 
-__global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
+__global__ void __launch_bounds__(kIngThreads, 6) k_ingest_parse(IngestArgs a) {
   __shared__ __align__(16) unsigned char s_text[kIngChunk + kIngLook + 16];
   __shared__ int s_w[kIngThreads / 64];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -271,13 +295,14 @@ __global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
         for (int b = o; b < want; ++b) s_text[b] = a.text[cbase + b];
       }
     }
+    if (tid == 0) s_text[want] = (unsigned char)'\n';     // sentinel: the parser stops at a newline
     __syncthreads();
     const int64_t base = cbase + (int64_t)tid * kIngPerThread;
-    uint32_t w[16];
-    uint32_t prev = 0, next2 = 0;
-    int cnt = 0;
+    // line starts in this thread's 64 bytes, then the data rows among them (first one or two bytes)
     const int o = tid * kIngPerThread;
+    unsigned long long dmask = 0;
     if (base < a.n_bytes) {
+      uint32_t w[16];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -289,12 +314,18 @@ __global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
         }
         w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
       }
-      prev = base == 0 ? (uint32_t)'\n' : (tid == 0 ? (uint32_t)a.text[base - 1] : (uint32_t)s_text[o - 1]);
-      const uint32_t n0 = o + kIngPerThread < want ? s_text[o + kIngPerThread] : 0u;
-      const uint32_t n1 = o + kIngPerThread + 1 < want ? s_text[o + kIngPerThread + 1] : 0u;
-      next2 = n0 | (n1 << 8);
-      ing_row_starts(w, prev, next2, base, a.n_bytes, [&](int) { ++cnt; });
+      const uint32_t prev = base == 0 ? (uint32_t)'\n' : (tid == 0 ? (uint32_t)a.text[base - 1] : (uint32_t)s_text[o - 1]);
+      unsigned long long smask = ing_line_start_mask(w, prev);
+      const int64_t left = a.n_bytes - base;                 // bytes of text from this thread's first byte on
+      if (left < 64) smask &= (1ull << left) - 1ull;
+      for (unsigned long long m = smask; m; m &= m - 1ull) {
+        const int k = __ffsll((long long)m) - 1;
+        const uint32_t c0 = s_text[o + k];
+        const uint32_t c1 = k + 1 < left ? (uint32_t)s_text[o + k + 1] : 0u;
+        if (ing_data_row(c0, c1)) dmask |= 1ull << k;
+      }
     }
+    const int cnt = __popcll(dmask);
     // rank of this thread's first row inside the chunk
     int incl = cnt;
 #pragma unroll
@@ -304,18 +335,14 @@ __global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
     int woff = 0;
     for (int k = 0; k < wave; ++k) woff += s_w[k];
     long long row = a.chunk_rows[c] + woff + incl - cnt;
-    if (cnt > 0) {
-      ing_row_starts(w, prev, next2, base, a.n_bytes, [&](int k) {
-        IngCursor cur;
-        cur.s = s_text;
-        cur.p = o + k;
-        cur.lim = want;
-        int32_t oid = 0, pidx = -1, qty = 0;
-        const bool ok = ing_row(cur, a, oid, pidx, qty);
-        if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
-        if (row < a.capacity) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }
-        ++row;
-      });
+    for (unsigned long long m = dmask; m; m &= m - 1ull, ++row) {
+      IngCursor cur;
+      cur.s = s_text;
+      cur.p = o + __ffsll((long long)m) - 1;
+      int32_t oid = 0, pidx = -1, qty = 0;
+      const bool ok = ing_row(cur, a, oid, pidx, qty);
+      if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
+      if (row < a.capacity) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }
     }
     __syncthreads();
   }
