@@ -280,6 +280,8 @@ __device__ __forceinline__ bool ing_row(IngCursor& c, const IngestArgs& a, int32
 
 __global__ void __launch_bounds__(kIngThreads, 6) k_ingest_parse(IngestArgs a) {
   __shared__ __align__(16) unsigned char s_text[kIngChunk + kIngLook + 16];
+  // start offsets of the chunk's data rows, in text order (a data row takes at least two bytes)
+  __shared__ unsigned short s_row[kIngChunk / 2];
   __shared__ int s_w[kIngThreads / 64];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned long long bad = 0;
@@ -332,16 +334,23 @@ __global__ void __launch_bounds__(kIngThreads, 6) k_ingest_parse(IngestArgs a) {
     for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
     if (lane == 63) s_w[wave] = incl;
     __syncthreads();
-    int woff = 0;
-    for (int k = 0; k < wave; ++k) woff += s_w[k];
-    long long row = a.chunk_rows[c] + woff + incl - cnt;
-    for (unsigned long long m = dmask; m; m &= m - 1ull, ++row) {
+    int woff = 0, n_r = 0;
+#pragma unroll
+    for (int k = 0; k < kIngThreads / 64; ++k) { if (k < wave) woff += s_w[k]; n_r += s_w[k]; }
+    // hand the rows out one per thread: every lane of a wave then parses a row of its own, and
+    // consecutive lanes write consecutive output rows
+    int r = woff + incl - cnt;
+    for (unsigned long long m = dmask; m; m &= m - 1ull, ++r) s_row[r] = (unsigned short)(o + __ffsll((long long)m) - 1);
+    __syncthreads();
+    const long long rbase = a.chunk_rows[c];
+    for (r = tid; r < n_r; r += kIngThreads) {
       IngCursor cur;
       cur.s = s_text;
-      cur.p = o + __ffsll((long long)m) - 1;
+      cur.p = (int)s_row[r];
       int32_t oid = 0, pidx = -1, qty = 0;
       const bool ok = ing_row(cur, a, oid, pidx, qty);
       if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
+      const long long row = rbase + r;
       if (row < a.capacity) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }
     }
     __syncthreads();
