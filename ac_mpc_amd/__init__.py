@@ -8,6 +8,6 @@ from . import _lib
 _lib.load()          # fail loudly, at import, if the HIP extension has not been built
 
 from .lote import ErrorLote, MotorLote, consultasLote, formato_subtotal   # noqa: E402
-from . import ingesta, reparto, sintetico                                            # noqa: E402
+from . import emision, ingesta, reparto, sintetico                                   # noqa: E402
 
-__all__ = ["ErrorLote", "MotorLote", "consultasLote", "formato_subtotal", "ingesta", "reparto", "sintetico"]
+__all__ = ["ErrorLote", "MotorLote", "consultasLote", "formato_subtotal", "emision", "ingesta", "reparto", "sintetico"]

@@ -17,10 +17,13 @@ EXPORTS = (
     "acmpc_aggregate", "acmpc_aggregate_device", "acmpc_status", "acmpc_set_option", "acmpc_set_profiling",
     "acmpc_last_kernel_ms", "acmpc_lines_geometry", "acmpc_synth_plan", "acmpc_synth_prices",
     "acmpc_synth_generate_device", "acmpc_set_product_codes", "acmpc_ingest_detalle_device", "acmpc_ingest_detalle",
+    "acmpc_emit_totals_device", "acmpc_emit_stock_device", "acmpc_emit_totals", "acmpc_emit_stock",
 )
 
 OK, E_INVALID, E_HIP, E_ALIGN, E_DATA, E_STATE, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
 ST_ORDER_RANGE, ST_ORDER_UNSORTED, ST_CUSTOMER_RANGE, ST_INGEST_MALFORMED, ST_INGEST_CAPACITY = 1, 2, 4, 8, 16
+ST_EMIT_CAPACITY = 32
+EMIT_SQL, EMIT_CSV = 0, 1
 OPT_LINE_ORDER, ORDER_GROUPED, ORDER_ANY = 1, 0, 1
 K_LINES, K_FIXUP, K_CUSTOMERS, K_CUSTMERGE, N_KERNELS = 0, 1, 2, 3, 4
 
@@ -105,5 +108,13 @@ def load() -> C.CDLL:
     lib.acmpc_ingest_detalle_device.restype = C.c_int
     lib.acmpc_ingest_detalle.argtypes = [vp, vp, i64, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     lib.acmpc_ingest_detalle.restype = C.c_int
+    lib.acmpc_emit_totals_device.argtypes = [vp, vp, i64, i32, C.c_int, vp, i64, vp, vp]
+    lib.acmpc_emit_totals_device.restype = C.c_int
+    lib.acmpc_emit_stock_device.argtypes = [vp, vp, i32, C.c_int, vp, i64, vp, vp]
+    lib.acmpc_emit_stock_device.restype = C.c_int
+    lib.acmpc_emit_totals.argtypes = [vp, vp, i64, i32, C.c_int, vp, i64, C.POINTER(i64)]
+    lib.acmpc_emit_totals.restype = C.c_int
+    lib.acmpc_emit_stock.argtypes = [vp, vp, i32, C.c_int, vp, i64, C.POINTER(i64)]
+    lib.acmpc_emit_stock.restype = C.c_int
     _lib = lib
     return lib

@@ -2,6 +2,7 @@
 // include/acmpc.h.  Device code is in acmpc_kernels.hpp.  gfx950 only; no CPU backend.
 #include "acmpc_kernels.hpp"
 #include "acmpc_ingest.hpp"
+#include "acmpc_emit.hpp"
 #include "../../include/acmpc.h"
 
 #include <algorithm>
@@ -66,6 +67,11 @@ struct acmpc_ctx {
   DevBuf<long long> d_chunk_rows;
   long long* d_ing_scalars = nullptr;      // [0] rows found, [1] malformed rows
   DevBuf<unsigned char> s_text;
+  int32_t code_sql_bad = -1, code_csv_bad = -1;   // first code a text style cannot carry, or -1
+
+  // text emit: chunk sizes, byte counter
+  DevBuf<long long> d_chunk_bytes;
+  DevBuf<int64_t> s_emit_value;
 
   // tuning (environment overrides, read once)
   int k1_threads = 1024;
@@ -483,7 +489,7 @@ ACMPC_API void acmpc_destroy(acmpc_ctx* ctx) {
   release(ctx->s_order_total); release(ctx->s_product_qty); release(ctx->s_customer_total);
   release(ctx->s_synth_off); release(ctx->s_synth_cdf);
   release(ctx->d_dict_hash); release(ctx->d_codes); release(ctx->d_dict_idx); release(ctx->d_chunk_rows);
-  release(ctx->s_text);
+  release(ctx->s_text); release(ctx->d_chunk_bytes); release(ctx->s_emit_value);
   if (ctx->d_ing_scalars) (void)hipFree(ctx->d_ing_scalars);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   for (int i = 0; i <= ACMPC_N_KERNELS; ++i)
@@ -694,11 +700,18 @@ ACMPC_API int acmpc_set_product_codes(acmpc_ctx* ctx, const char* codes32, int32
   while (size < 2u * (uint32_t)n_products + 2u) size <<= 1;
   std::vector<unsigned long long> hash(size, 0ull), codes((size_t)n_products * 4, 0ull);
   std::vector<int32_t> idx(size, -1);
+  int32_t sql_bad = -1, csv_bad = -1;
   for (int32_t i = 0; i < n_products; ++i) {
     const char* c = codes32 + (size_t)i * 32;
     size_t len = 0;
     while (len < 32 && c[len]) ++len;
     if (len > 30) return fail(ctx, ACMPC_E_INVALID, "product code %d is longer than 30 bytes (varchar(30), store.sql:110)", i);
+    if (sql_bad < 0 && (memchr(c, '\'', len) || memchr(c, '\\', len))) sql_bad = i;
+    if (csv_bad < 0) {
+      bool bad = len == 0 || c[0] == '\'' || c[0] == '"';
+      for (size_t k = 0; k < len && !bad; ++k) bad = strchr(",\t \r\n)", c[k]) != nullptr;
+      if (bad) csv_bad = i;
+    }
     for (size_t k = 0; k < len; ++k)
       codes[(size_t)i * 4 + (k >> 3)] |= (unsigned long long)(unsigned char)c[k] << (8 * (k & 7));
     const unsigned long long kw[4] = {codes[(size_t)i * 4], codes[(size_t)i * 4 + 1], codes[(size_t)i * 4 + 2],
@@ -723,6 +736,8 @@ ACMPC_API int acmpc_set_product_codes(acmpc_ctx* ctx, const char* codes32, int32
   if (!ctx->d_ing_scalars) HIPCHK(ctx, hipMalloc((void**)&ctx->d_ing_scalars, 2 * sizeof(long long)));
   ctx->dict_mask = size - 1;
   ctx->dict_products = n_products;
+  ctx->code_sql_bad = sql_bad;
+  ctx->code_csv_bad = csv_bad;
   return ACMPC_OK;
 }
 
@@ -758,7 +773,8 @@ ACMPC_API int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, in
   const int blocks = (int)std::min<int64_t>(a.n_chunks, (int64_t)ctx->n_cu * 8);
   hipLaunchKernelGGL(k_ingest_count, dim3(blocks), dim3(kIngThreads), 0, st, a);
   HIPCHK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_ingest_scan, dim3(1), dim3(1024), 0, st, a);
+  ScanArgs sc{a.chunk_rows, a.n_chunks, a.n_rows, capacity_rows, a.status, kStIngestCapacity};
+  hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, st, sc);
   HIPCHK(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_ingest_parse, dim3(blocks), dim3(kIngThreads), 0, st, a);
   HIPCHK(ctx, hipGetLastError());
@@ -798,4 +814,120 @@ ACMPC_API int acmpc_ingest_detalle(acmpc_ctx* ctx, const char* text, int64_t n_b
   }
   uint32_t flags = 0;
   return acmpc_status(ctx, st, &flags);
+}
+
+// ---- text emit ---------------------------------------------------------------------------
+
+namespace {
+
+template <int Kind, int Style>
+int launch_emit(acmpc_ctx* ctx, const EmitArgs& a, hipStream_t st) {
+  const int blocks = (int)std::min<int64_t>(a.n_chunks, (int64_t)ctx->n_cu * 16);
+  hipLaunchKernelGGL((k_emit_count<Kind, Style>), dim3(blocks), dim3(kEmitThreads), 0, st, a);
+  HIPCHK(ctx, hipGetLastError());
+  ScanArgs sc{a.chunk_bytes, a.n_chunks, a.n_bytes, a.capacity, a.status, kStEmitCapacity};
+  hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, st, sc);
+  HIPCHK(ctx, hipGetLastError());
+  hipLaunchKernelGGL((k_emit_write<Kind, Style>), dim3(blocks), dim3(kEmitThreads), 0, st, a);
+  HIPCHK(ctx, hipGetLastError());
+  return ACMPC_OK;
+}
+
+int emit_device_impl(acmpc_ctx* ctx, const char* who, int kind, const int64_t* d_value, int64_t n_rows,
+                     int64_t order_id_base, int style, char* d_text, int64_t capacity, int64_t* d_n_bytes,
+                     hipStream_t st) {
+  if (style != ACMPC_EMIT_SQL && style != ACMPC_EMIT_CSV) return fail(ctx, ACMPC_E_INVALID, "%s: unknown style %d", who, style);
+  if (n_rows < 0 || capacity < 0 || !d_n_bytes) return fail(ctx, ACMPC_E_INVALID, "%s: bad size or null byte counter", who);
+  if (n_rows > 0 && !d_value) return fail(ctx, ACMPC_E_INVALID, "%s: null value pointer", who);
+  if (capacity > 0 && !d_text) return fail(ctx, ACMPC_E_INVALID, "%s: null text pointer", who);
+  if (!aligned16(d_text)) return fail(ctx, ACMPC_E_ALIGN, "%s: device text must be 16-byte aligned", who);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  EmitArgs a;
+  a.value = reinterpret_cast<const long long*>(d_value);
+  a.n_rows = n_rows;
+  a.n_chunks = (n_rows + kEmitChunkRows - 1) / kEmitChunkRows;
+  a.order_id_base = order_id_base;
+  a.codes = ctx->d_codes.p;
+  int rc;
+  if ((rc = ensure(ctx, ctx->d_chunk_bytes, (size_t)a.n_chunks + 1))) return rc;
+  a.chunk_bytes = ctx->d_chunk_bytes.p;
+  a.text = reinterpret_cast<unsigned char*>(d_text);
+  a.capacity = capacity;
+  a.n_bytes = reinterpret_cast<long long*>(d_n_bytes);
+  a.status = ctx->d_status;
+  if (a.n_chunks == 0) {
+    HIPCHK(ctx, hipMemsetAsync(d_n_bytes, 0, sizeof(int64_t), st));
+    return ACMPC_OK;
+  }
+  if (kind == kEmitTotals)
+    return style == ACMPC_EMIT_SQL ? launch_emit<kEmitTotals, kEmitSql>(ctx, a, st) : launch_emit<kEmitTotals, kEmitCsv>(ctx, a, st);
+  return style == ACMPC_EMIT_SQL ? launch_emit<kEmitStock, kEmitSql>(ctx, a, st) : launch_emit<kEmitStock, kEmitCsv>(ctx, a, st);
+}
+
+int emit_host_impl(acmpc_ctx* ctx, const char* who, int kind, const int64_t* value, int64_t n_rows, int64_t base,
+                   int style, char* text, int64_t capacity, int64_t* n_bytes) {
+  if (!n_bytes || n_rows < 0 || capacity < 0 || (n_rows > 0 && !value) || (capacity > 0 && !text))
+    return fail(ctx, ACMPC_E_INVALID, "%s: bad argument", who);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->s_emit_value, (size_t)n_rows))) return rc;
+  if ((rc = ensure(ctx, ctx->s_text, (size_t)capacity + 16))) return rc;
+  if (!ctx->d_ing_scalars) HIPCHK(ctx, hipMalloc((void**)&ctx->d_ing_scalars, 2 * sizeof(long long)));
+  hipStream_t st = nullptr;
+  if (n_rows > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->s_emit_value.p, value, (size_t)n_rows * 8, hipMemcpyHostToDevice, st));
+  rc = kind == kEmitTotals
+           ? acmpc_emit_totals_device(ctx, ctx->s_emit_value.p, n_rows, (int32_t)base, style,
+                                      reinterpret_cast<char*>(ctx->s_text.p), capacity,
+                                      reinterpret_cast<int64_t*>(ctx->d_ing_scalars), st)
+           : acmpc_emit_stock_device(ctx, ctx->s_emit_value.p, (int32_t)n_rows, style,
+                                     reinterpret_cast<char*>(ctx->s_text.p), capacity,
+                                     reinterpret_cast<int64_t*>(ctx->d_ing_scalars), st);
+  if (rc) return rc;
+  long long need = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&need, ctx->d_ing_scalars, sizeof(need), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  *n_bytes = need;
+  const int64_t got = std::min<int64_t>(need, capacity);
+  if (got > 0) HIPCHK(ctx, hipMemcpy(text, ctx->s_text.p, (size_t)got, hipMemcpyDeviceToHost));
+  uint32_t flags = 0;
+  return acmpc_status(ctx, st, &flags);
+}
+
+}  // namespace
+
+ACMPC_API int acmpc_emit_totals_device(acmpc_ctx* ctx, const int64_t* d_order_total_cents, int64_t n_orders,
+                                       int32_t order_id_base, int style, char* d_text, int64_t capacity_bytes,
+                                       int64_t* d_n_bytes, void* hip_stream) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_emit_totals_device: null context");
+  if (n_orders > 0 && (int64_t)order_id_base + n_orders - 1 > INT32_MAX)
+    return fail(ctx, ACMPC_E_INVALID, "acmpc_emit_totals_device: order ids would leave int32 (NumPedido is INT, store.sql:159)");
+  return emit_device_impl(ctx, "acmpc_emit_totals_device", kEmitTotals, d_order_total_cents, n_orders, order_id_base,
+                          style, d_text, capacity_bytes, d_n_bytes, (hipStream_t)hip_stream);
+}
+
+ACMPC_API int acmpc_emit_stock_device(acmpc_ctx* ctx, const int64_t* d_product_qty, int32_t n_products, int style,
+                                      char* d_text, int64_t capacity_bytes, int64_t* d_n_bytes, void* hip_stream) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_emit_stock_device: null context");
+  if (ctx->dict_products <= 0) return fail(ctx, ACMPC_E_STATE, "acmpc_set_product_codes has not been called");
+  if (n_products != ctx->dict_products)
+    return fail(ctx, ACMPC_E_INVALID, "acmpc_emit_stock_device: %d deltas for a code list of %d", n_products, ctx->dict_products);
+  const int32_t bad = style == ACMPC_EMIT_SQL ? ctx->code_sql_bad : style == ACMPC_EMIT_CSV ? ctx->code_csv_bad : -1;
+  if (bad >= 0) return fail(ctx, ACMPC_E_DATA, "product code %d cannot be written unescaped in this style", bad);
+  return emit_device_impl(ctx, "acmpc_emit_stock_device", kEmitStock, d_product_qty, n_products, 0, style, d_text,
+                          capacity_bytes, d_n_bytes, (hipStream_t)hip_stream);
+}
+
+ACMPC_API int acmpc_emit_totals(acmpc_ctx* ctx, const int64_t* order_total_cents, int64_t n_orders,
+                                int32_t order_id_base, int style, char* text, int64_t capacity_bytes, int64_t* n_bytes) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_emit_totals: null context");
+  return emit_host_impl(ctx, "acmpc_emit_totals", kEmitTotals, order_total_cents, n_orders, order_id_base, style, text,
+                        capacity_bytes, n_bytes);
+}
+
+ACMPC_API int acmpc_emit_stock(acmpc_ctx* ctx, const int64_t* product_qty, int32_t n_products, int style, char* text,
+                               int64_t capacity_bytes, int64_t* n_bytes) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_emit_stock: null context");
+  if (n_products < 0) return fail(ctx, ACMPC_E_INVALID, "acmpc_emit_stock: negative size");
+  return emit_host_impl(ctx, "acmpc_emit_stock", kEmitStock, product_qty, n_products, 0, style, text, capacity_bytes,
+                        n_bytes);
 }

@@ -147,35 +147,6 @@ __global__ void __launch_bounds__(kIngThreads) k_ingest_count(IngestArgs a) {
   }
 }
 
-// Exclusive prefix sum of chunk_rows[0..n) in place; chunk_rows[n] and *n_rows receive the total.
-__global__ void __launch_bounds__(1024) k_ingest_scan(IngestArgs a) {
-  __shared__ long long s_w[16];
-  __shared__ long long s_carry;
-  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int64_t i0 = 0; i0 < a.n_chunks; i0 += 1024) {
-    const int64_t i = i0 + tid;
-    const long long v = i < a.n_chunks ? a.chunk_rows[i] : 0;
-    long long incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const long long t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    long long off = s_carry;
-    for (int k = 0; k < wave; ++k) off += s_w[k];
-    if (i < a.n_chunks) a.chunk_rows[i] = off + incl - v;
-    __syncthreads();
-    if (tid == 1023) s_carry = off + incl;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    a.chunk_rows[a.n_chunks] = s_carry;
-    *a.n_rows = s_carry;
-    if (s_carry > a.capacity) atomicOr(a.status, kStIngestCapacity);
-  }
-}
-
 // Hash of a product code given as its 32 NUL-padded bytes in four little-endian 64-bit words.
 __host__ __device__ __forceinline__ unsigned long long ing_code_hash(const unsigned long long (&k)[4]) {
   unsigned long long h = k[0] * 0x9E3779B97F4A7C15ull;
@@ -278,7 +249,7 @@ __device__ __forceinline__ bool ing_row(IngCursor& c, const IngestArgs& a, int32
   return true;
 }
 
-__global__ void __launch_bounds__(kIngThreads, 6) k_ingest_parse(IngestArgs a) {
+__global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
   __shared__ __align__(16) unsigned char s_text[kIngChunk + kIngLook + 16];
   // start offsets of the chunk's data rows, in text order (a data row takes at least two bytes)
   __shared__ unsigned short s_row[kIngChunk / 2];

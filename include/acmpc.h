@@ -213,6 +213,54 @@ int acmpc_ingest_detalle(acmpc_ctx* ctx, const char* text, int64_t n_bytes,
                          int64_t capacity_rows, int64_t* n_rows, int64_t* n_malformed);
 
 /* ------------------------------------------------------------------------
+ * Text emit: results -> the statements that would store them back in the shop's tables.
+ *
+ * The reference keeps `venta.TotalPagar` (DECIMAL(30,2), store.sql:163, written once by
+ * process/confirmcompra.php:24) and `producto.Stock` (INT, store.sql:116, never decremented).
+ * Every statement has the shape consultasSQL::UpdateSQL builds, library/consulSQL.php:43-44
+ * ("update $tabla set $campos where $condicion"), with values quoted the way
+ * process/updatePedido.php:11 quotes them; one row per line, rows in index order.
+ *
+ *   totals, ACMPC_EMIT_SQL   update venta set TotalPagar='2200.00' where NumPedido='5';\n
+ *   totals, ACMPC_EMIT_CSV   5,2200.00\n
+ *   stock,  ACMPC_EMIT_SQL   update producto set Stock=Stock-3 where CodigoProd='1';\n
+ *                            (Stock=Stock+3 when the delta is negative)
+ *   stock,  ACMPC_EMIT_CSV   1,3\n                    (code, signed delta)
+ *
+ * An amount is integer cents written as [-]units.cc, the text MariaDB prints for a DECIMAL(30,2).
+ * Every order gets a totals row (order id = order_id_base + index).  A product whose delta is zero
+ * gets no stock row.  Stock rows need the code list of acmpc_set_product_codes; a code that the
+ * style cannot carry unescaped (SQL: ' or \ ; CSV: , tab space CR LF ) or a leading quote, or an
+ * empty code) makes the call fail with ACMPC_E_DATA before anything is written.
+ * Upper bounds for sizing: 83 bytes per totals row, 103 per stock row.
+ * ---------------------------------------------------------------------- */
+#define ACMPC_EMIT_SQL 0
+#define ACMPC_EMIT_CSV 1
+#define ACMPC_ST_EMIT_CAPACITY 32u /* acmpc_emit_*: the text needs more than capacity_bytes */
+
+/* Write the audit rows of n_orders DEVICE totals into DEVICE text (16-byte aligned) of
+ * capacity_bytes.  *d_n_bytes (device int64) receives the bytes the full text needs; when that
+ * exceeds capacity_bytes only the first capacity_bytes are written and ACMPC_ST_EMIT_CAPACITY is
+ * raised.  Enqueued on hip_stream. */
+int acmpc_emit_totals_device(acmpc_ctx* ctx, const int64_t* d_order_total_cents, int64_t n_orders,
+                             int32_t order_id_base, int style, char* d_text, int64_t capacity_bytes,
+                             int64_t* d_n_bytes, void* hip_stream);
+
+/* Write the stock rows of the DEVICE deltas product_qty[n_products] (n_products must equal the
+ * length of the code list). */
+int acmpc_emit_stock_device(acmpc_ctx* ctx, const int64_t* d_product_qty, int32_t n_products,
+                            int style, char* d_text, int64_t capacity_bytes, int64_t* d_n_bytes,
+                            void* hip_stream);
+
+/* Same from HOST results into HOST text; they wait, and return ACMPC_E_DATA when capacity_bytes
+ * was too small (*n_bytes then still holds the size needed). */
+int acmpc_emit_totals(acmpc_ctx* ctx, const int64_t* order_total_cents, int64_t n_orders,
+                      int32_t order_id_base, int style, char* text, int64_t capacity_bytes,
+                      int64_t* n_bytes);
+int acmpc_emit_stock(acmpc_ctx* ctx, const int64_t* product_qty, int32_t n_products, int style,
+                     char* text, int64_t capacity_bytes, int64_t* n_bytes);
+
+/* ------------------------------------------------------------------------
  * Synthetic store.sql-schema data, integer-only and reproducible bit for bit
  * on host and device.  These have no counterpart in the reference (which ships
  * three products and one customer, store.sql:89,126-128); they exist so that

@@ -32,6 +32,10 @@ class Oracle:
         lib.oracle_synth_fill.restype = None
         lib.oracle_ingest_detalle.argtypes = [vp, i64, vp, i32, vp, vp, vp, i64, C.POINTER(i64)]
         lib.oracle_ingest_detalle.restype = i64
+        lib.oracle_emit_totals.argtypes = [vp, i64, i32, C.c_int, vp, i64]
+        lib.oracle_emit_totals.restype = i64
+        lib.oracle_emit_stock.argtypes = [vp, i32, vp, C.c_int, vp, i64]
+        lib.oracle_emit_stock.restype = i64
         self.lib = lib
 
     def aggregate(self, order_id, product_idx, qty, order_customer, order_id_base, n_customers, price_cents):
@@ -86,3 +90,20 @@ class Oracle:
                                                pidx.ctypes.data, qty.ctypes.data, capacity, C.byref(bad)))
         k = min(n, capacity)
         return oid[:k], pidx[:k], qty[:k], n, int(bad.value)
+
+    def emit_totals(self, total_cents, order_id_base, style, capacity=None) -> bytes:
+        """Audit rows of the per-order totals as the C oracle writes them."""
+        v = np.ascontiguousarray(total_cents, np.int64)
+        cap = v.size * 90 + 1 if capacity is None else capacity
+        buf = C.create_string_buffer(max(cap, 1))
+        n = int(self.lib.oracle_emit_totals(v.ctypes.data, v.size, int(order_id_base), style, buf, cap))
+        return buf.raw[:min(n, cap)]
+
+    def emit_stock(self, product_qty, codes, style) -> bytes:
+        from ac_mpc_amd.ingesta import empaquetar_codigos
+        v = np.ascontiguousarray(product_qty, np.int64)
+        packed = empaquetar_codigos(codes)
+        cap = v.size * 110 + 1
+        buf = C.create_string_buffer(cap)
+        n = int(self.lib.oracle_emit_stock(v.ctypes.data, v.size, packed.ctypes.data, style, buf, cap))
+        return buf.raw[:n]
