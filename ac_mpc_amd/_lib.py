@@ -17,6 +17,7 @@ EXPORTS = (
     "acmpc_aggregate", "acmpc_aggregate_device", "acmpc_status", "acmpc_set_option", "acmpc_set_profiling",
     "acmpc_last_kernel_ms", "acmpc_lines_geometry", "acmpc_synth_plan", "acmpc_synth_prices",
     "acmpc_synth_generate_device", "acmpc_set_product_codes", "acmpc_ingest_detalle_device", "acmpc_ingest_detalle",
+    "acmpc_aggregate_lifecycle", "acmpc_aggregate_lifecycle_device",
     "acmpc_emit_totals_device", "acmpc_emit_stock_device", "acmpc_emit_totals", "acmpc_emit_stock",
 )
 
@@ -24,6 +25,7 @@ OK, E_INVALID, E_HIP, E_ALIGN, E_DATA, E_STATE, E_NOMEM = 0, -1, -2, -3, -4, -5,
 ST_ORDER_RANGE, ST_ORDER_UNSORTED, ST_CUSTOMER_RANGE, ST_INGEST_MALFORMED, ST_INGEST_CAPACITY = 1, 2, 4, 8, 16
 ST_EMIT_CAPACITY = 32
 EMIT_SQL, EMIT_CSV = 0, 1
+ORDER_COUNTS, DESCUENTO_UNITS, DESCUENTO_PERCENT = 1, 0, 1
 OPT_LINE_ORDER, ORDER_GROUPED, ORDER_ANY = 1, 0, 1
 K_LINES, K_FIXUP, K_CUSTOMERS, K_CUSTMERGE, N_KERNELS = 0, 1, 2, 3, 4
 
@@ -37,6 +39,11 @@ class SynthCfg(C.Structure):
 class SynthShard(C.Structure):
     _fields_ = [("n_orders_total", C.c_int64), ("order_lo", C.c_int64), ("order_hi", C.c_int64),
                 ("line_lo", C.c_int64), ("line_hi", C.c_int64)]
+
+
+class Lifecycle(C.Structure):
+    _fields_ = [("line_price_cents", C.c_void_p), ("order_state", C.c_void_p), ("order_descuento", C.c_void_p),
+                ("descuento_mode", C.c_int32)]
 
 
 _lib = None
@@ -108,6 +115,11 @@ def load() -> C.CDLL:
     lib.acmpc_ingest_detalle_device.restype = C.c_int
     lib.acmpc_ingest_detalle.argtypes = [vp, vp, i64, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     lib.acmpc_ingest_detalle.restype = C.c_int
+    lp = C.POINTER(Lifecycle)
+    lib.acmpc_aggregate_lifecycle.argtypes = [vp, vp, vp, vp, i64, vp, i64, i32, i32, lp, vp, vp, vp]
+    lib.acmpc_aggregate_lifecycle.restype = C.c_int
+    lib.acmpc_aggregate_lifecycle_device.argtypes = [vp, vp, vp, vp, i64, vp, i64, i32, i32, lp, vp, vp, vp, vp]
+    lib.acmpc_aggregate_lifecycle_device.restype = C.c_int
     lib.acmpc_emit_totals_device.argtypes = [vp, vp, i64, i32, C.c_int, vp, i64, vp, vp]
     lib.acmpc_emit_totals_device.restype = C.c_int
     lib.acmpc_emit_stock_device.argtypes = [vp, vp, i32, C.c_int, vp, i64, vp, vp]

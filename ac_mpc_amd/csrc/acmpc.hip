@@ -56,6 +56,9 @@ struct acmpc_ctx {
   // staging buffers of the host-pointer entry point
   DevBuf<int32_t> s_order_id, s_product_idx, s_qty, s_order_customer;
   DevBuf<int64_t> s_order_total, s_product_qty, s_customer_total;
+  DevBuf<int64_t> s_line_price;
+  DevBuf<unsigned char> s_order_state;
+  DevBuf<int32_t> s_order_descuento;
   DevBuf<int64_t> s_synth_off;
   DevBuf<unsigned long long> s_synth_cdf;
 
@@ -150,17 +153,21 @@ struct LinesPlan {
   int n_active_waves;
 };
 
-int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p) {
+// line_prices: the grouped kernel reads a line-price column (lifecycle): no price table in LDS, and a
+// 2 KB slice per wave for re-ordering the price loads.
+int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p, bool line_prices = false) {
   // tables hold P + 1 entries (the null product): int32 or int64 prices + 32-bit histogram
   const size_t need32 = (size_t)ctx->p_pad * 8, need64 = (size_t)ctx->p_pad * 12;
   p->price32 = ctx->price_fits32;
-  p->lds_bytes = p->price32 ? need32 : need64;
+  p->lds_bytes = line_prices ? (size_t)ctx->p_pad * 4 : p->price32 ? need32 : need64;
   p->threads = ctx->k1_threads;
   p->waves_per_block = p->threads / kWave;
   p->lpl = (p->price32 && ctx->k1_lpl == 8) ? 8 : 4;
   p->tile_lines = kWave * p->lpl;
   // besides the tables every wave stages finished order totals: stage_cap slots + 64 scratch slots
-  auto stage_bytes = [&](uint32_t cap) { return (size_t)p->waves_per_block * (cap + kWave) * 8; };
+  auto stage_bytes = [&](uint32_t cap) {
+    return (size_t)p->waves_per_block * ((cap + kWave) * 8 + (line_prices ? 2048 : 0));
+  };
   p->lds_tables = !ctx->force_global_tables && p->lds_bytes + stage_bytes(kTile) + kLdsReserve <= (size_t)kMaxLds;
   if (!p->lds_tables) { p->lds_bytes = 0; p->price32 = false; p->lpl = 4; p->tile_lines = kTile; }
   p->stage_cap = 512;
@@ -234,9 +241,9 @@ int clear_carries(acmpc_ctx* ctx, hipStream_t st) {
   return ACMPC_OK;
 }
 
-template <typename PriceT, bool kLds, int LPL>
+template <typename PriceT, bool kLds, int LPL, bool kLife = false>
 int launch_lines(acmpc_ctx* ctx, const LinesPlan& pl, const LinesArgs& a, hipStream_t st) {
-  auto kern = k_lines<PriceT, kLds, LPL>;
+  auto kern = k_lines<PriceT, kLds, LPL, kLife>;
   {
     int rc = set_dyn_lds(ctx, kern, pl.lds_bytes);
     if (rc) return rc;
@@ -246,9 +253,9 @@ int launch_lines(acmpc_ctx* ctx, const LinesPlan& pl, const LinesArgs& a, hipStr
   return ACMPC_OK;
 }
 
-template <typename PriceT, bool kLds>
+template <typename PriceT, bool kLds, bool kLife = false>
 int launch_lines_any(acmpc_ctx* ctx, const LinesPlan& pl, size_t lds_bytes, const LinesArgs& a, hipStream_t st) {
-  auto kern = k_lines_any<PriceT, kLds>;
+  auto kern = k_lines_any<PriceT, kLds, kLife>;
   if (lds_bytes) {
     int rc = set_dyn_lds(ctx, kern, lds_bytes);
     if (rc) return rc;
@@ -261,8 +268,18 @@ int launch_lines_any(acmpc_ctx* ctx, const LinesPlan& pl, size_t lds_bytes, cons
 int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32_t* d_product_idx,
                           const int32_t* d_qty, int64_t n_lines, const int32_t* d_order_customer,
                           int64_t n_orders, int32_t base, int32_t n_customers, int64_t* d_tot,
-                          int64_t* d_pq, int64_t* d_ct, hipStream_t st) {
+                          int64_t* d_pq, int64_t* d_ct, hipStream_t st, const acmpc_lifecycle* life = nullptr) {
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_aggregate_device: null context");
+  const int64_t* d_line_price = life ? life->line_price_cents : nullptr;
+  const uint8_t* d_state = life ? life->order_state : nullptr;
+  const int32_t* d_desc = life ? life->order_descuento : nullptr;
+  if (life) {
+    if (d_desc && life->descuento_mode != ACMPC_DESCUENTO_UNITS && life->descuento_mode != ACMPC_DESCUENTO_PERCENT)
+      return fail(ctx, ACMPC_E_INVALID, "unknown descuento_mode %d", life->descuento_mode);
+    if (!aligned16(d_line_price) || !aligned16(d_state) || !aligned16(d_desc))
+      return fail(ctx, ACMPC_E_ALIGN, "lifecycle columns must be 16-byte aligned");
+  }
+  const bool life_lines = d_line_price || d_state;
   if (ctx->n_products <= 0) return fail(ctx, ACMPC_E_STATE, "acmpc_set_products has not been called");
   if (n_lines < 0 || n_orders < 0 || n_customers <= 0)
     return fail(ctx, ACMPC_E_INVALID, "negative size or n_customers <= 0");
@@ -285,18 +302,24 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
 
   // ---- order-line pass ------------------------------------------------------------------
   LinesPlan lp;
-  plan_lines(ctx, n_lines, &lp);
   const bool any_order = ctx->line_order == ACMPC_ORDER_ANY;
-  if (any_order && lp.lpl != 4) {            // the any-order kernel works on 256-line tiles
+  const bool xpose_prices = d_line_price && !any_order;
+  plan_lines(ctx, n_lines, &lp, xpose_prices);
+  if ((any_order || life_lines) && lp.lpl != 4) {   // these kernels work on 256-line tiles
     const int keep = ctx->k1_lpl;
     ctx->k1_lpl = 4;
-    plan_lines(ctx, n_lines, &lp);
+    plan_lines(ctx, n_lines, &lp, xpose_prices);
     ctx->k1_lpl = keep;
   }
   int rc;
   if (n_lines == 0) {
     if (n_orders > 0) HIPCHK(ctx, hipMemsetAsync(d_tot, 0, (size_t)n_orders * 8, st));
     HIPCHK(ctx, hipMemsetAsync(d_pq, 0, (size_t)P * 8, st));
+    if (d_desc && n_orders > 0) {
+      hipLaunchKernelGGL(k_order_adjust, dim3((unsigned)((n_orders + 255) / 256)), dim3(256), 0, st, d_tot, d_desc,
+                         n_orders, life->descuento_mode);
+      HIPCHK(ctx, hipGetLastError());
+    }
     if (ctx->profiling) { HIPCHK(ctx, hipEventRecord(ctx->ev[1], st)); HIPCHK(ctx, hipEventRecord(ctx->ev[2], st)); }
   } else {
     if ((rc = ensure(ctx, ctx->d_prod_carry, (size_t)ctx->p_pad, true))) return rc;
@@ -320,14 +343,27 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     }
     a.order_total = d_tot; a.prod_slab = ctx->d_prod_slab.p; a.prod_carry = ctx->d_prod_carry.p;
     a.rec_id = ctx->d_rec_id.p; a.rec_sum = ctx->d_rec_sum.p; a.status = ctx->d_status;
+    a.line_price = reinterpret_cast<const long long*>(d_line_price);
+    a.price_in_lds = xpose_prices ? 0 : 1;
+    a.order_state = d_state;
 
     ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
     if (any_order) {
       HIPCHK(ctx, hipMemsetAsync(d_tot, 0, (size_t)n_orders * 8, st));
       const size_t tables = lp.lds_tables ? (size_t)ctx->p_pad * (lp.price32 ? 8 : 12) : 0;
-      if (!lp.lds_tables) rc = launch_lines_any<int64_t, false>(ctx, lp, tables, a, st);
+      if (life_lines) {
+        if (!lp.lds_tables) rc = launch_lines_any<int64_t, false, true>(ctx, lp, tables, a, st);
+        else if (lp.price32) rc = launch_lines_any<int32_t, true, true>(ctx, lp, tables, a, st);
+        else rc = launch_lines_any<int64_t, true, true>(ctx, lp, tables, a, st);
+      }
+      else if (!lp.lds_tables) rc = launch_lines_any<int64_t, false>(ctx, lp, tables, a, st);
       else if (lp.price32) rc = launch_lines_any<int32_t, true>(ctx, lp, tables, a, st);
       else rc = launch_lines_any<int64_t, true>(ctx, lp, tables, a, st);
+    }
+    else if (life_lines) {
+      if (!lp.lds_tables) rc = launch_lines<int64_t, false, 4, true>(ctx, lp, a, st);
+      else if (lp.price32) rc = launch_lines<int32_t, true, 4, true>(ctx, lp, a, st);
+      else rc = launch_lines<int64_t, true, 4, true>(ctx, lp, a, st);
     }
     else if (!lp.lds_tables) rc = launch_lines<int64_t, false, 4>(ctx, lp, a, st);
     else if (lp.price32 && lp.lpl == 8) rc = launch_lines<int32_t, true, 8>(ctx, lp, a, st);
@@ -353,6 +389,11 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       hipLaunchKernelGGL(k_move_clear, dim3((P + 255) / 256), dim3(256), 0, st, ctx->d_prod_carry.p, d_pq, P);
       HIPCHK(ctx, hipGetLastError());
     }
+    if (d_desc) {                 // totals are final after k_fixup: take the discounts off
+      hipLaunchKernelGGL(k_order_adjust, dim3((unsigned)((n_orders + 255) / 256)), dim3(256), 0, st, d_tot, d_desc,
+                         n_orders, life->descuento_mode);
+      HIPCHK(ctx, hipGetLastError());
+    }
     if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
   }
 
@@ -374,10 +415,16 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     c.n_streams = cp.n_streams; c.cust_slab = ctx->d_cust_slab.p; c.cust_carry = ctx->d_cust_carry.p;
     c.status = ctx->d_status;
     c.ablate = env_int("ACMPC_K2_ABLATE", 0);
+    c.order_state = d_state;
     ctx->carry_dirty = true;
-    if (cp.lds_tables) {
+    if (cp.lds_tables && d_state) {
+      if ((rc = set_dyn_lds(ctx, k_customers<true, true>, cp.lds_bytes))) return rc;
+      hipLaunchKernelGGL((k_customers<true, true>), dim3(cp.blocks), dim3(cp.threads), cp.lds_bytes, st, c);
+    } else if (cp.lds_tables) {
       if ((rc = set_dyn_lds(ctx, k_customers<true>, cp.lds_bytes))) return rc;
       hipLaunchKernelGGL(k_customers<true>, dim3(cp.blocks), dim3(cp.threads), cp.lds_bytes, st, c);
+    } else if (d_state) {
+      hipLaunchKernelGGL((k_customers<false, true>), dim3(cp.blocks), dim3(cp.threads), 0, st, c);
     } else {
       hipLaunchKernelGGL(k_customers<false>, dim3(cp.blocks), dim3(cp.threads), 0, st, c);
     }
@@ -490,6 +537,7 @@ ACMPC_API void acmpc_destroy(acmpc_ctx* ctx) {
   release(ctx->s_synth_off); release(ctx->s_synth_cdf);
   release(ctx->d_dict_hash); release(ctx->d_codes); release(ctx->d_dict_idx); release(ctx->d_chunk_rows);
   release(ctx->s_text); release(ctx->d_chunk_bytes); release(ctx->s_emit_value);
+  release(ctx->s_line_price); release(ctx->s_order_state); release(ctx->s_order_descuento);
   if (ctx->d_ing_scalars) (void)hipFree(ctx->d_ing_scalars);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   for (int i = 0; i <= ACMPC_N_KERNELS; ++i)
@@ -528,6 +576,17 @@ ACMPC_API int acmpc_aggregate_device(acmpc_ctx* ctx, const int32_t* d_order_id, 
                                d_out_customer_total_cents, (hipStream_t)hip_stream);
 }
 
+ACMPC_API int acmpc_aggregate_lifecycle_device(acmpc_ctx* ctx, const int32_t* d_order_id, const int32_t* d_product_idx,
+                                               const int32_t* d_qty, int64_t n_lines, const int32_t* d_order_customer,
+                                               int64_t n_orders, int32_t order_id_base, int32_t n_customers,
+                                               const acmpc_lifecycle* life, int64_t* d_out_order_total_cents,
+                                               int64_t* d_out_product_qty, int64_t* d_out_customer_total_cents,
+                                               void* hip_stream) {
+  return aggregate_device_impl(ctx, d_order_id, d_product_idx, d_qty, n_lines, d_order_customer, n_orders,
+                               order_id_base, n_customers, d_out_order_total_cents, d_out_product_qty,
+                               d_out_customer_total_cents, (hipStream_t)hip_stream, life);
+}
+
 ACMPC_API int acmpc_status(acmpc_ctx* ctx, void* hip_stream, uint32_t* flags) {
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_status: null context");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -552,6 +611,16 @@ ACMPC_API int acmpc_aggregate(acmpc_ctx* ctx, const int32_t* order_id, const int
                               int64_t n_orders, int32_t order_id_base, int32_t n_customers,
                               int64_t* out_order_total_cents, int64_t* out_product_qty,
                               int64_t* out_customer_total_cents) {
+  return acmpc_aggregate_lifecycle(ctx, order_id, product_idx, qty, n_lines, order_customer, n_orders, order_id_base,
+                                   n_customers, nullptr, out_order_total_cents, out_product_qty,
+                                   out_customer_total_cents);
+}
+
+ACMPC_API int acmpc_aggregate_lifecycle(acmpc_ctx* ctx, const int32_t* order_id, const int32_t* product_idx,
+                                        const int32_t* qty, int64_t n_lines, const int32_t* order_customer,
+                                        int64_t n_orders, int32_t order_id_base, int32_t n_customers,
+                                        const acmpc_lifecycle* life, int64_t* out_order_total_cents,
+                                        int64_t* out_product_qty, int64_t* out_customer_total_cents) {
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_aggregate: null context");
   if (ctx->n_products <= 0) return fail(ctx, ACMPC_E_STATE, "acmpc_set_products has not been called");
   if (n_lines < 0 || n_orders < 0 || n_customers <= 0) return fail(ctx, ACMPC_E_INVALID, "negative size or n_customers <= 0");
@@ -576,9 +645,28 @@ ACMPC_API int acmpc_aggregate(acmpc_ctx* ctx, const int32_t* order_id, const int
   }
   if (n_orders > 0)
     HIPCHK(ctx, hipMemcpyAsync(ctx->s_order_customer.p, order_customer, (size_t)n_orders * 4, hipMemcpyHostToDevice, st));
+  acmpc_lifecycle dl = {nullptr, nullptr, nullptr, 0};
+  if (life) {
+    dl.descuento_mode = life->descuento_mode;
+    if (life->line_price_cents && n_lines > 0) {
+      if ((rc = ensure(ctx, ctx->s_line_price, (size_t)n_lines))) return rc;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->s_line_price.p, life->line_price_cents, (size_t)n_lines * 8, hipMemcpyHostToDevice, st));
+      dl.line_price_cents = ctx->s_line_price.p;
+    }
+    if (life->order_state && n_orders > 0) {
+      if ((rc = ensure(ctx, ctx->s_order_state, (size_t)n_orders))) return rc;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->s_order_state.p, life->order_state, (size_t)n_orders, hipMemcpyHostToDevice, st));
+      dl.order_state = ctx->s_order_state.p;
+    }
+    if (life->order_descuento && n_orders > 0) {
+      if ((rc = ensure(ctx, ctx->s_order_descuento, (size_t)n_orders))) return rc;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->s_order_descuento.p, life->order_descuento, (size_t)n_orders * 4, hipMemcpyHostToDevice, st));
+      dl.order_descuento = ctx->s_order_descuento.p;
+    }
+  }
   rc = aggregate_device_impl(ctx, ctx->s_order_id.p, ctx->s_product_idx.p, ctx->s_qty.p, n_lines,
                              ctx->s_order_customer.p, n_orders, order_id_base, n_customers, ctx->s_order_total.p,
-                             ctx->s_product_qty.p, ctx->s_customer_total.p, st);
+                             ctx->s_product_qty.p, ctx->s_customer_total.p, st, life ? &dl : nullptr);
   if (rc) return rc;
   if (n_orders > 0)
     HIPCHK(ctx, hipMemcpyAsync(out_order_total_cents, ctx->s_order_total.p, (size_t)n_orders * 8, hipMemcpyDeviceToHost, st));

@@ -59,7 +59,28 @@ struct LinesArgs {
   int32_t* rec_id;          // [2 * waves]  head/tail order id of every wave
   int64_t* rec_sum;         // [2 * waves]  head/tail partial sums
   uint32_t* status;
+  // order lifecycle (kLife kernels only; each may be null)
+  const long long* line_price;        // [n_lines] price at the time of sale, instead of the table
+  int32_t price_in_lds;               // 0: no price table in LDS (line prices make it unnecessary)
+  const unsigned char* order_state;   // [M] bit 0: the order counts towards stock and customer sums
 };
+
+// Lifecycle: quantities that reach the stock delta (0 for lines of orders that do not count).
+template <int LPL>
+__device__ __forceinline__ void live_quantities(const LinesArgs& a, const int (&ids)[LPL], const int (&qs)[LPL],
+                                                int (&qh)[LPL]) {
+  if (a.order_state) {
+    const uint32_t top = (uint32_t)a.n_orders - 1u;         // n_orders > 0 whenever there are lines
+    unsigned char s[LPL];
+#pragma unroll
+    for (int i = 0; i < LPL; ++i) s[i] = a.order_state[min((uint32_t)ids[i] - (uint32_t)a.base, top)];
+#pragma unroll
+    for (int i = 0; i < LPL; ++i) qh[i] = (s[i] & 1) ? qs[i] : 0;
+  } else {
+#pragma unroll
+    for (int i = 0; i < LPL; ++i) qh[i] = qs[i];
+  }
+}
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
 
@@ -164,11 +185,14 @@ __device__ __forceinline__ void stage_flush(const LinesArgs& a, long long* s_sta
 // Tables carry one extra entry, index P, the "null product": price 0 and a scratch histogram
 // cell.  Any product_idx outside [0, P) is clamped to it with one unsigned min, so unknown codes
 // need no branch and add nothing.
-template <typename PriceT, bool kLdsTables, int LPL>
+//
+// kLife: `qh` holds the quantities that reach the stock delta (see live_quantities) and, when `snap`
+// is not null, snap[i] is the line's own price; otherwise qh is qs and the table price is used.
+template <typename PriceT, bool kLdsTables, int LPL, bool kLife = false>
 __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_price, uint32_t* s_hist,
                                            long long* s_stage, const int (&ids)[LPL], const int (&prs)[LPL],
                                            const int (&qs)[LPL], int lane, uint32_t lt_lo, uint32_t lt_hi,
-                                           WaveRun& o) {
+                                           WaveRun& o, const int (&qh)[LPL], const long long* snap = nullptr) {
   const uint32_t P = (uint32_t)a.n_products;
   uint32_t pi[LPL];
   long long v[LPL];
@@ -176,25 +200,31 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
 #pragma unroll
   for (int i = 0; i < LPL; ++i) pi[i] = min((uint32_t)prs[i], P);
   if (kLdsTables) {
-    PriceT price[LPL];
-#pragma unroll
-    for (int i = 0; i < LPL; ++i) price[i] = s_price[pi[i]];
     // Stock delta: every quantity is added to the 32-bit LDS histogram with a non-returning add.
     // The host sizes q_small so that a workgroup's sum of quantities below q_small cannot wrap; a
     // quantity outside [0, q_small) (never produced by the reference, which always writes 1) is
     // detected through qmax, taken back out of the histogram and sent to a 64-bit global atomic.
 #pragma unroll
     for (int i = 0; i < LPL; ++i) {
-      __hip_atomic_fetch_add(&s_hist[pi[i]], (uint32_t)qs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      qmax = max(qmax, (uint32_t)qs[i]);
+      __hip_atomic_fetch_add(&s_hist[pi[i]], (uint32_t)qh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      qmax = max(qmax, (uint32_t)qh[i]);
     }
+    if (kLife && snap) {
 #pragma unroll
-    for (int i = 0; i < LPL; ++i) v[i] = (long long)price[i] * (long long)qs[i];
+      for (int i = 0; i < LPL; ++i) v[i] = (pi[i] < P ? snap[i] : 0ll) * (long long)qs[i];
+    } else {
+      PriceT price[LPL];
+#pragma unroll
+      for (int i = 0; i < LPL; ++i) price[i] = s_price[pi[i]];
+#pragma unroll
+      for (int i = 0; i < LPL; ++i) v[i] = (long long)price[i] * (long long)qs[i];
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < LPL; ++i) {
-      v[i] = a.price[pi[i]] * (long long)qs[i];
-      if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qs[i]);
+      const long long pr = (kLife && snap) ? (pi[i] < P ? snap[i] : 0ll) : a.price[pi[i]];
+      v[i] = pr * (long long)qs[i];
+      if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qh[i]);
     }
   }
 
@@ -272,9 +302,9 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
   if (kLdsTables) {
 #pragma unroll
     for (int i = 0; i < LPL; ++i) {
-      if ((uint32_t)qs[i] >= a.q_small) {
-        __hip_atomic_fetch_add(&s_hist[pi[i]], 0u - (uint32_t)qs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qs[i]);
+      if ((uint32_t)qh[i] >= a.q_small) {
+        __hip_atomic_fetch_add(&s_hist[pi[i]], 0u - (uint32_t)qh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qh[i]);
       }
     }
   }
@@ -318,8 +348,45 @@ __device__ __forceinline__ void load_lines(const int32_t* p, int (&out)[LPL]) {
   }
 }
 
-template <typename PriceT, bool kLdsTables, int LPL>
+// The 256 int64 line prices of a tile (2 KB, `tile` points at the tile's first line) as two fully
+// coalesced 16-byte streaming loads per lane: load k brings prices 128k + 2*lane and 128k + 2*lane + 1.
+// (Letting every lane load its own four prices directly makes each load touch half of every cache
+// line, and the lines are then fetched twice.)
+__device__ __forceinline__ void load_prices_raw(const long long* tile, int lane, int4 (&raw)[2]) {
+  const int32_t* p = reinterpret_cast<const int32_t*>(tile);
+  raw[0] = load_stream16(p + lane * 4);
+  raw[1] = load_stream16(p + 256 + lane * 4);
+}
+
+// Hands every lane the prices of its own four lines (4*lane .. 4*lane+3) through the wave's 2 KB LDS
+// slice.  LDS operations of one wave execute in order, so no barrier is needed.
+__device__ __forceinline__ void own_prices(int4* xp, int lane, const int4 (&raw)[2], long long (&out)[4]) {
+  xp[lane] = raw[0];
+  xp[64 + lane] = raw[1];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int4 a = xp[2 * lane], b = xp[2 * lane + 1];
+  out[0] = (long long)(((unsigned long long)(uint32_t)a.y << 32) | (uint32_t)a.x);
+  out[1] = (long long)(((unsigned long long)(uint32_t)a.w << 32) | (uint32_t)a.z);
+  out[2] = (long long)(((unsigned long long)(uint32_t)b.y << 32) | (uint32_t)b.x);
+  out[3] = (long long)(((unsigned long long)(uint32_t)b.w << 32) | (uint32_t)b.z);
+  __builtin_amdgcn_wave_barrier();                   // the slice is rewritten for the next tile
+}
+
+// LPL consecutive int64 prices of the line-price column for this lane (strided; any-order kernel).
+template <int LPL>
+__device__ __forceinline__ void load_prices(const long long* p, long long (&out)[LPL]) {
+#pragma unroll
+  for (int k = 0; k < LPL / 2; ++k) {
+    const int4 x = load_stream16(reinterpret_cast<const int32_t*>(p + 2 * k));
+    out[2 * k] = (long long)(((unsigned long long)(uint32_t)x.y << 32) | (uint32_t)x.x);
+    out[2 * k + 1] = (long long)(((unsigned long long)(uint32_t)x.w << 32) | (uint32_t)x.z);
+  }
+}
+
+template <typename PriceT, bool kLdsTables, int LPL, bool kLife = false>
 __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
+  static_assert(!kLife || LPL == 4, "lifecycle columns are read four lines per lane");
   constexpr int kTileL = kWave * LPL;                 // lines per wave-tile
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
@@ -328,15 +395,20 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
   const int P1 = a.n_products + 1;                    // tables include the null product
   // LDS: [price table][stock-delta histogram] (only with kLdsTables), then per wave a staging slice
   // of stage_cap slots followed by 64 scratch slots.
-  const size_t tables = kLdsTables ? (size_t)a.p_pad * (sizeof(PriceT) + sizeof(uint32_t)) : 0;
+  // With line prices (lifecycle) the price table is left out and every wave gets a 2 KB slice, after
+  // the staging slices, through which it re-orders the coalesced price loads.
+  const bool price_lds = !kLife || a.price_in_lds != 0;
+  const size_t price_bytes = (kLdsTables && price_lds) ? (size_t)a.p_pad * sizeof(PriceT) : 0;
+  const size_t tables = kLdsTables ? price_bytes + (size_t)a.p_pad * sizeof(uint32_t) : 0;
   PriceT* s_price = reinterpret_cast<PriceT*>(smem);
-  uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + (size_t)a.p_pad * sizeof(PriceT));
+  uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + price_bytes);
   long long* s_stage = reinterpret_cast<long long*>(smem + tables) + (size_t)wave * (a.stage_cap + kWave);
+  int4* s_xpose = reinterpret_cast<int4*>(smem + tables + (size_t)waves_per_block * (a.stage_cap + kWave) * 8) + wave * 128;
 
   for (uint32_t k = (uint32_t)lane; k < a.stage_cap; k += kWave) s_stage[k] = 0;
   if (kLdsTables) {
     for (int i = (int)threadIdx.x; i < P1; i += (int)blockDim.x) {
-      s_price[i] = (PriceT)a.price[i];
+      if (price_lds) s_price[i] = (PriceT)a.price[i];
       s_hist[i] = 0u;
     }
     __syncthreads();
@@ -367,18 +439,31 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
       const long long last = tf - 1;
       long long off = t0 * kTileL + lane * LPL;
       int nid[LPL], npr[LPL], nq[LPL];
+      int4 nraw[2] = {};
+      const bool snapped = kLife && a.line_price != nullptr;
       load_lines<LPL>(a.order_id + off, nid);
       load_lines<LPL>(a.product_idx + off, npr);
       load_lines<LPL>(a.qty + off, nq);
+      if constexpr (kLife) { if (snapped) load_prices_raw(a.line_price + (off - lane * LPL), lane, nraw); }
       for (long long t = t0; t <= last; ++t) {
         int ids[LPL], prs[LPL], qs[LPL];
+        long long sn[4];
 #pragma unroll
         for (int i = 0; i < LPL; ++i) { ids[i] = nid[i]; prs[i] = npr[i]; qs[i] = nq[i]; }
+        if constexpr (kLife) { if (snapped) own_prices(s_xpose, lane, nraw, sn); }
         off += (t < last) ? kTileL : 0;
         load_lines<LPL>(a.order_id + off, nid);
         load_lines<LPL>(a.product_idx + off, npr);
         load_lines<LPL>(a.qty + off, nq);
-        lines_tile<PriceT, kLdsTables, LPL>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o);
+        if constexpr (kLife) { if (snapped) load_prices_raw(a.line_price + (off - lane * LPL), lane, nraw); }
+        if constexpr (kLife) {
+          int qh[LPL];
+          live_quantities<LPL>(a, ids, qs, qh);
+          lines_tile<PriceT, kLdsTables, LPL, true>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qh,
+                                                    snapped ? sn : nullptr);
+        } else {
+          lines_tile<PriceT, kLdsTables, LPL>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs);
+        }
       }
     }
     if (tf < t1) {
@@ -394,7 +479,18 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
         prs[i] = in ? a.product_idx[l] : -1;
         qs[i] = in ? a.qty[l] : 0;
       }
-      lines_tile<PriceT, kLdsTables, LPL>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o);
+      if constexpr (kLife) {
+        long long sn[LPL];
+        int qh[LPL];
+        const bool snapped = a.line_price != nullptr;
+#pragma unroll
+        for (int i = 0; i < LPL; ++i) sn[i] = (snapped && l0 + i < a.n_lines) ? a.line_price[l0 + i] : 0ll;
+        live_quantities<LPL>(a, ids, qs, qh);
+        lines_tile<PriceT, kLdsTables, LPL, true>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qh,
+                                                  snapped ? sn : nullptr);
+      } else {
+        lines_tile<PriceT, kLdsTables, LPL>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs);
+      }
     }
     // orders closed since the last flush (everything below the order that is still open)
     stage_flush(a, s_stage, o, min(((uint32_t)o.id - (uint32_t)a.base) - o.buf_base, a.stage_cap), lane);
@@ -425,7 +521,7 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
 // still combined inside a tile (one 64-bit global atomic per run), so almost-grouped input costs about
 // one atomic per order; fully shuffled input costs one per line.
 // ---------------------------------------------------------------------------------------------
-template <typename PriceT, bool kLdsTables>
+template <typename PriceT, bool kLdsTables, bool kLife = false>
 __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
   constexpr int LPL = kLinesPerLane;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -433,11 +529,12 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
   const int wave = (int)(threadIdx.x >> 6);
   const int waves_per_block = (int)(blockDim.x >> 6);
   const uint32_t P = (uint32_t)a.n_products;
+  const bool price_lds = !kLife || a.price_in_lds != 0;
   PriceT* s_price = reinterpret_cast<PriceT*>(smem);
-  uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + (size_t)a.p_pad * sizeof(PriceT));
+  uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + (price_lds ? (size_t)a.p_pad * sizeof(PriceT) : 0));
   if (kLdsTables) {
     for (int i = (int)threadIdx.x; i < (int)P + 1; i += (int)blockDim.x) {
-      s_price[i] = (PriceT)a.price[i];
+      if (price_lds) s_price[i] = (PriceT)a.price[i];
       s_hist[i] = 0u;
     }
     __syncthreads();
@@ -453,11 +550,14 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
   uint32_t st = 0;
   for (long long t = t0; t < t1; ++t) {
     const long long l0 = t * kTile + (long long)lane * LPL;
-    int ids[LPL], prs[LPL], qs[LPL];
+    int ids[LPL], prs[LPL], qs[LPL], qh[LPL];
+    long long sn[LPL];
+    const bool snapped = kLife && a.line_price != nullptr;
     if (l0 + LPL <= a.n_lines) {
       load_lines<LPL>(a.order_id + l0, ids);
       load_lines<LPL>(a.product_idx + l0, prs);
       load_lines<LPL>(a.qty + l0, qs);
+      if (snapped) load_prices<LPL>(a.line_price + l0, sn);
     } else {
       // past the end: repeat the last real order id of the data set, unknown product, quantity 0
       const int last_id = a.order_id[a.n_lines - 1];
@@ -467,7 +567,13 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
         ids[i] = in ? a.order_id[l0 + i] : last_id;
         prs[i] = in ? a.product_idx[l0 + i] : -1;
         qs[i] = in ? a.qty[l0 + i] : 0;
+        sn[i] = (snapped && in) ? a.line_price[l0 + i] : 0ll;
       }
+    }
+    if (kLife) live_quantities<LPL>(a, ids, qs, qh);
+    else {
+#pragma unroll
+      for (int i = 0; i < LPL; ++i) qh[i] = qs[i];
     }
     uint32_t pi[LPL];
     long long v[LPL];
@@ -476,21 +582,22 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
     for (int i = 0; i < LPL; ++i) pi[i] = min((uint32_t)prs[i], P);
 #pragma unroll
     for (int i = 0; i < LPL; ++i) {
+      const long long own = pi[i] < P ? sn[i] : 0ll;        // the line's own price (lifecycle)
       if (kLdsTables) {
-        v[i] = (long long)s_price[pi[i]] * (long long)qs[i];
-        __hip_atomic_fetch_add(&s_hist[pi[i]], (uint32_t)qs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        qmax = max(qmax, (uint32_t)qs[i]);
+        v[i] = (snapped ? own : (long long)s_price[price_lds ? pi[i] : 0]) * (long long)qs[i];
+        __hip_atomic_fetch_add(&s_hist[pi[i]], (uint32_t)qh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        qmax = max(qmax, (uint32_t)qh[i]);
       } else {
-        v[i] = a.price[pi[i]] * (long long)qs[i];
-        if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qs[i]);
+        v[i] = (snapped ? own : a.price[pi[i]]) * (long long)qs[i];
+        if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qh[i]);
       }
     }
     if (kLdsTables && qmax >= a.q_small) {
 #pragma unroll
       for (int i = 0; i < LPL; ++i) {
-        if ((uint32_t)qs[i] >= a.q_small) {
-          __hip_atomic_fetch_add(&s_hist[pi[i]], 0u - (uint32_t)qs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qs[i]);
+        if ((uint32_t)qh[i] >= a.q_small) {
+          __hip_atomic_fetch_add(&s_hist[pi[i]], 0u - (uint32_t)qh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qh[i]);
         }
       }
     }
@@ -716,6 +823,7 @@ struct CustArgs {
   unsigned long long* cust_carry;  // [C] high-word corrections (LDS mode) / the totals (global mode)
   uint32_t* status;
   int32_t ablate;                  // developer switch: 1 = skip the LDS adds (timing experiments only)
+  const unsigned char* order_state;   // [M] or null (kLife kernels): bit 0 = the order counts
 };
 
 // One tile of 256 orders: lane l holds orders 4l..4l+3 in (cs, tv).
@@ -769,7 +877,7 @@ __device__ __forceinline__ void customers_tile(const CustArgs& a, uint32_t* s_ta
 // Workgroup b: XCD label x = b % 8 (workgroups with equal label share an L2), slot j = b / 8,
 // range r = j % R, stream s = x + 8 * (j / R).  The R siblings of a stream read the same orders:
 // one of them brings a line in from HBM, the others find it in their XCD's L2.
-template <bool kLdsTables>
+template <bool kLdsTables, bool kLife = false>
 __global__ void __launch_bounds__(1024) k_customers(CustArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* s_tab = reinterpret_cast<uint32_t*>(smem);
@@ -808,6 +916,8 @@ __global__ void __launch_bounds__(1024) k_customers(CustArgs a) {
     const long long last = t + ((tf - 1 - t) / waves_per_block) * waves_per_block;   // this wave's last tile
     int4 rc[kCustDepth];
     longlong2 ra[kCustDepth], rb[kCustDepth];
+    uint32_t rs[kCustDepth];                              // four state bytes per lane (lifecycle)
+    const bool stated = kLife && a.order_state != nullptr;
 #pragma unroll
     for (int d = 0; d < kCustDepth; ++d) {
       long long tt = t + (long long)d * waves_per_block;
@@ -815,6 +925,7 @@ __global__ void __launch_bounds__(1024) k_customers(CustArgs a) {
       rc[d] = *reinterpret_cast<const int4*>(a.order_customer + tt * kTile + lane * 4);
       ra[d] = *reinterpret_cast<const longlong2*>(a.order_total + tt * kTile + lane * 4);
       rb[d] = *reinterpret_cast<const longlong2*>(a.order_total + tt * kTile + lane * 4 + 2);
+      rs[d] = stated ? *reinterpret_cast<const uint32_t*>(a.order_state + tt * kTile + lane * 4) : 0x01010101u;
     }
     for (; t <= last; t += (long long)kCustDepth * waves_per_block) {
 #pragma unroll
@@ -822,14 +933,20 @@ __global__ void __launch_bounds__(1024) k_customers(CustArgs a) {
         const long long tc = t + (long long)d * waves_per_block;
         const int4 c4 = rc[d];
         const longlong2 ta = ra[d], tb = rb[d];
+        const uint32_t s4 = rs[d];
         long long tn = tc + (long long)kCustDepth * waves_per_block;
         if (tn > last) tn = last;
         rc[d] = *reinterpret_cast<const int4*>(a.order_customer + tn * kTile + lane * 4);
         ra[d] = *reinterpret_cast<const longlong2*>(a.order_total + tn * kTile + lane * 4);
         rb[d] = *reinterpret_cast<const longlong2*>(a.order_total + tn * kTile + lane * 4 + 2);
+        if (stated) rs[d] = *reinterpret_cast<const uint32_t*>(a.order_state + tn * kTile + lane * 4);
         if (tc <= last) {
           const int cs[4] = {c4.x, c4.y, c4.z, c4.w};
-          const long long tv[4] = {ta.x, ta.y, tb.x, tb.y};
+          long long tv[4] = {ta.x, ta.y, tb.x, tb.y};
+          if (kLife) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tv[i] = ((s4 >> (8 * i)) & 1u) ? tv[i] : 0ll;
+          }
           customers_tile<kLdsTables>(a, s_tab, s_dummy, lo, len, cs, tv, lane, st);
         }
       }
@@ -847,6 +964,7 @@ __global__ void __launch_bounds__(1024) k_customers(CustArgs a) {
       const bool in = o0 + i < a.n_orders;
       cs[i] = in ? a.order_customer[o0 + i] : 0;
       tv[i] = in ? a.order_total[o0 + i] : 0;
+      if (kLife && a.order_state && in && !(a.order_state[o0 + i] & 1)) tv[i] = 0;
     }
     customers_tile<kLdsTables>(a, s_tab, s_dummy, lo, len, cs, tv, lane, st);
   }
@@ -895,6 +1013,26 @@ __global__ void __launch_bounds__(256) k_custmerge(CustMergeArgs a) {
                                    s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
     a.customer_total[c] = (int64_t)sum;
     a.cust_carry[c] = 0ull;           // leave the workspace clean for the next call
+  }
+}
+
+// venta.Descuento (INT, store.sql:162; always 0 in the reference, process/confirmcompra.php:24):
+// order_total[o] -= discount.  mode 0: the column is an amount in whole currency units; mode 1: a
+// percentage of the gross total, rounded half away from zero to a cent.  Wrapping 64-bit arithmetic.
+__device__ __forceinline__ long long descuento_cents(long long gross, int d, int mode) {
+  if (mode == 0) return 100ll * (long long)d;
+  const long long q = gross / 100ll, r = gross - q * 100ll;       // truncating: r has the sign of gross
+  const long long x = r * (long long)d;                           // |x| < 100 * 2^31
+  const long long part = x >= 0 ? (x + 50ll) / 100ll : -((-x + 50ll) / 100ll);
+  return (long long)((unsigned long long)q * (unsigned long long)(long long)d) + part;
+}
+
+__global__ void __launch_bounds__(256) k_order_adjust(int64_t* order_total, const int32_t* descuento, int64_t n_orders,
+                                                      int mode) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o < n_orders) {
+    const long long g = order_total[o];
+    order_total[o] = (int64_t)((unsigned long long)g - (unsigned long long)descuento_cents(g, descuento[o], mode));
   }
 }
 

@@ -73,13 +73,20 @@ class MotorLote:
         self.n_products = int(price.size)
 
     # -- host columns in, host results out ----------------------------------------------------
-    def agregar(self, order_id, product_idx, qty, order_customer, order_id_base: int, n_customers: int
+    def agregar(self, order_id, product_idx, qty, order_customer, order_id_base: int, n_customers: int,
+                precio_linea=None, estado_pedido=None, descuento=None, descuento_porcentaje: bool = False
                 ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """Return (order_total_cents[M], product_qty[P], customer_total_cents[C]).
 
         `order_id`, `product_idx`, `qty` are the `detalle` columns (store.sql:97-101) with the rows of
         each order contiguous and order ids non-decreasing; `order_customer[i]` is the customer index of
         order ``order_id_base + i``.
+
+        Order lifecycle (all optional): `precio_linea[N]` int64 cents, the price each line was sold at
+        (process/updateProduct.php:15 changes Precio later); `estado_pedido[M]` uint8, bit 0 set when the
+        order counts (cleared for an Estado that means cancelled, process/updatePedido.php:11, or a
+        deleted order, process/delPedido.php:12-13); `descuento[M]` int32, venta.Descuento (store.sql:162)
+        in whole currency units, or per cent with `descuento_porcentaje`.
         """
         oid, pidx, q = _np(order_id, np.int32), _np(product_idx, np.int32), _np(qty, np.int32)
         cust = _np(order_customer, np.int32)
@@ -91,33 +98,61 @@ class MotorLote:
         tot = np.empty(m, dtype=np.int64)
         pq = np.empty(self.n_products, dtype=np.int64)
         ct = np.empty(int(n_customers), dtype=np.int64)
-        self._check(self._lib.acmpc_aggregate(
+        keep = []
+        life = None
+        if precio_linea is not None or estado_pedido is not None or descuento is not None:
+            life = _lib.Lifecycle(None, None, None, _lib.DESCUENTO_PERCENT if descuento_porcentaje else _lib.DESCUENTO_UNITS)
+            for name, col, dt, size in (("line_price_cents", precio_linea, np.int64, n),
+                                        ("order_state", estado_pedido, np.uint8, m),
+                                        ("order_descuento", descuento, np.int32, m)):
+                if col is None:
+                    continue
+                arr = _np(col, dt)
+                if arr.ndim != 1 or arr.size != size:
+                    raise ErrorLote(_lib.E_INVALID, f"columna {name} de longitud incorrecta")
+                keep.append(arr)
+                setattr(life, name, arr.ctypes.data if arr.size else None)
+        self._check(self._lib.acmpc_aggregate_lifecycle(
             self._ctx, oid.ctypes.data, pidx.ctypes.data, q.ctypes.data, n, cust.ctypes.data, m,
-            int(order_id_base), int(n_customers), tot.ctypes.data, pq.ctypes.data, ct.ctypes.data))
+            int(order_id_base), int(n_customers), C.byref(life) if life is not None else None,
+            tot.ctypes.data, pq.ctypes.data, ct.ctypes.data))
         return tot, pq, ct
 
     # -- device-resident columns (torch tensors on this context's GPU) --------------------------
     def agregar_device(self, order_id, product_idx, qty, order_customer, order_id_base: int, n_customers: int,
-                       out_order_total, out_product_qty, out_customer_total, stream: Optional[int] = None) -> None:
+                       out_order_total, out_product_qty, out_customer_total, stream: Optional[int] = None,
+                       precio_linea=None, estado_pedido=None, descuento=None, descuento_porcentaje: bool = False
+                       ) -> None:
         """Enqueue the aggregation of device-resident columns; outputs are torch int64 CUDA tensors.
+        The lifecycle columns (see `agregar`) are torch CUDA tensors of int64 / uint8 / int32.
 
         Returns without waiting.  Call `estado()` to wait and check the data contract.
         """
         import torch
-        for t, dt in ((order_id, torch.int32), (product_idx, torch.int32), (qty, torch.int32),
-                      (order_customer, torch.int32), (out_order_total, torch.int64),
-                      (out_product_qty, torch.int64), (out_customer_total, torch.int64)):
+        n, m = order_id.numel(), order_customer.numel()
+        cols = [(order_id, torch.int32, n), (product_idx, torch.int32, n), (qty, torch.int32, n),
+                (order_customer, torch.int32, m), (out_order_total, torch.int64, m),
+                (out_product_qty, torch.int64, self.n_products), (out_customer_total, torch.int64, int(n_customers))]
+        life = None
+        if precio_linea is not None or estado_pedido is not None or descuento is not None:
+            life = _lib.Lifecycle(None, None, None, _lib.DESCUENTO_PERCENT if descuento_porcentaje else _lib.DESCUENTO_UNITS)
+            for name, t, dt, size in (("line_price_cents", precio_linea, torch.int64, n),
+                                      ("order_state", estado_pedido, torch.uint8, m),
+                                      ("order_descuento", descuento, torch.int32, m)):
+                if t is not None:
+                    cols.append((t, dt, size))
+                    setattr(life, name, t.data_ptr() if size else None)
+        for t, dt, size in cols:
             if not (t.is_cuda and t.dtype == dt and t.is_contiguous() and t.device.index == self.device):
                 raise ErrorLote(_lib.E_INVALID, "tensor de tipo, dispositivo o disposicion incorrectos")
-        n, m = order_id.numel(), order_customer.numel()
-        if product_idx.numel() != n or qty.numel() != n or out_order_total.numel() != m or \
-                out_product_qty.numel() != self.n_products or out_customer_total.numel() != int(n_customers):
-            raise ErrorLote(_lib.E_INVALID, "longitudes de columnas o resultados incoherentes")
+            if t.numel() != size:
+                raise ErrorLote(_lib.E_INVALID, "longitudes de columnas o resultados incoherentes")
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
-        self._check(self._lib.acmpc_aggregate_device(
+        self._check(self._lib.acmpc_aggregate_lifecycle_device(
             self._ctx, order_id.data_ptr(), product_idx.data_ptr(), qty.data_ptr(), n,
             order_customer.data_ptr(), m, int(order_id_base), int(n_customers),
+            C.byref(life) if life is not None else None,
             out_order_total.data_ptr(), out_product_qty.data_ptr(), out_customer_total.data_ptr(), stream))
 
     def estado(self, stream: Optional[int] = None) -> int:

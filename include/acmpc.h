@@ -136,6 +136,61 @@ int acmpc_aggregate_device(acmpc_ctx* ctx,
                            void* hip_stream);
 
 /*
+ * Order lifecycle: optional columns that make the sums right over time, not only for a frozen
+ * snapshot of the tables.  Every pointer may be NULL (= the column is absent).
+ *
+ *   line_price_cents[N]  the price each line was sold at, in cents.  process/updateProduct.php:15
+ *                        can change producto.Precio after a sale, while venta.TotalPagar keeps the
+ *                        sum at sale time (process/confirmcompra.php:24).  When given, a line of a
+ *                        known product contributes line_price_cents * qty instead of the table
+ *                        price; an unknown product still adds nothing.
+ *   order_state[M]       bit 0 (ACMPC_ORDER_COUNTS) set: the order counts.  Clear it for an order
+ *                        whose venta.Estado (process/updatePedido.php:11) says it was cancelled, or
+ *                        whose venta row was removed (process/delPedido.php:12-13).  Such an order
+ *                        still gets its total (the audit value of its TotalPagar) but adds nothing
+ *                        to the stock deltas or to its customer's total.
+ *   order_descuento[M]   venta.Descuento (INT, store.sql:162; the reference always stores 0,
+ *                        process/confirmcompra.php:24), taken off the order's total:
+ *                          ACMPC_DESCUENTO_UNITS    an amount in whole currency units (100 cents each)
+ *                          ACMPC_DESCUENTO_PERCENT  per cent of the gross total, the discount rounded
+ *                                                   half away from zero to a cent
+ *                        Customer totals add the discounted totals.
+ * Arithmetic wraps in 64 bits like everything else.  Device pointers must be 16-byte aligned.
+ * No counterpart in the reference, which never recomputes a total.
+ */
+#define ACMPC_ORDER_COUNTS       1u
+#define ACMPC_DESCUENTO_UNITS    0
+#define ACMPC_DESCUENTO_PERCENT  1
+typedef struct acmpc_lifecycle {
+  const int64_t* line_price_cents;
+  const uint8_t* order_state;
+  const int32_t* order_descuento;
+  int32_t        descuento_mode;
+} acmpc_lifecycle;
+
+/* acmpc_aggregate / acmpc_aggregate_device with the lifecycle columns (`life` may be NULL; its
+ * pointers are host pointers for the first, device pointers for the second). */
+int acmpc_aggregate_lifecycle(acmpc_ctx* ctx,
+                              const int32_t* order_id, const int32_t* product_idx, const int32_t* qty,
+                              int64_t n_lines,
+                              const int32_t* order_customer, int64_t n_orders,
+                              int32_t order_id_base, int32_t n_customers,
+                              const acmpc_lifecycle* life,
+                              int64_t* out_order_total_cents,
+                              int64_t* out_product_qty,
+                              int64_t* out_customer_total_cents);
+int acmpc_aggregate_lifecycle_device(acmpc_ctx* ctx,
+                                     const int32_t* d_order_id, const int32_t* d_product_idx,
+                                     const int32_t* d_qty, int64_t n_lines,
+                                     const int32_t* d_order_customer, int64_t n_orders,
+                                     int32_t order_id_base, int32_t n_customers,
+                                     const acmpc_lifecycle* life,
+                                     int64_t* d_out_order_total_cents,
+                                     int64_t* d_out_product_qty,
+                                     int64_t* d_out_customer_total_cents,
+                                     void* hip_stream);
+
+/*
  * Wait for `hip_stream`, then store in *flags the OR of ACMPC_ST_* bits raised
  * by device calls since the previous acmpc_status(), and clear them.
  * Returns ACMPC_OK when *flags == 0, ACMPC_E_DATA otherwise.

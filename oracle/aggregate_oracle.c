@@ -79,6 +79,66 @@ ORACLE_API int oracle_aggregate(const int32_t* order_id, const int32_t* product_
   return flags;
 }
 
+/*
+ * The same walk with the order-lifecycle columns (each may be NULL):
+ *   line_price_cents[l]  price at the time of sale: process/updateProduct.php:15 may change
+ *                        producto.Precio later, venta.TotalPagar keeps the old sum
+ *                        (process/confirmcompra.php:24);
+ *   order_state[o]       bit 0 clear: cancelled through venta.Estado (process/updatePedido.php:11)
+ *                        or deleted (process/delPedido.php:12-13): the order keeps its total but
+ *                        adds nothing to stock deltas and customer totals;
+ *   order_descuento[o]   venta.Descuento (store.sql:162): mode 0 = whole currency units,
+ *                        mode 1 = per cent of the gross total, rounded half away from zero to a cent.
+ * The reference has no code for any of this; the definitions are the build's own.
+ */
+ORACLE_API int oracle_aggregate_lifecycle(const int32_t* order_id, const int32_t* product_idx,
+                                          const int32_t* qty, int64_t n_lines,
+                                          const int32_t* order_customer, int64_t n_orders,
+                                          int32_t order_id_base, int32_t n_customers,
+                                          const int64_t* price_cents, int32_t n_products,
+                                          const int64_t* line_price_cents, const uint8_t* order_state,
+                                          const int32_t* order_descuento, int32_t descuento_mode,
+                                          int64_t* order_total_cents, int64_t* product_qty,
+                                          int64_t* customer_total_cents)
+{
+  int flags = 0;
+  uint64_t* tot = (uint64_t*)order_total_cents;
+  uint64_t* pq = (uint64_t*)product_qty;
+  uint64_t* ct = (uint64_t*)customer_total_cents;
+  memset(tot, 0, (size_t)n_orders * sizeof(uint64_t));
+  memset(pq, 0, (size_t)n_products * sizeof(uint64_t));
+  memset(ct, 0, (size_t)n_customers * sizeof(uint64_t));
+  for (int64_t l = 0; l < n_lines; ++l) {
+    if (l > 0 && order_id[l] < order_id[l - 1]) flags |= 2;
+    int64_t o = (int64_t)order_id[l] - (int64_t)order_id_base;
+    if (o < 0 || o >= n_orders) { flags |= 1; continue; }
+    int32_t p = product_idx[l];
+    if (p < 0 || p >= n_products) continue;
+    uint64_t q = (uint64_t)(int64_t)qty[l];
+    uint64_t price = (uint64_t)(line_price_cents ? line_price_cents[l] : price_cents[p]);
+    tot[o] += price * q;
+    if (!order_state || (order_state[o] & 1)) pq[p] += q;
+  }
+  for (int64_t o = 0; o < n_orders; ++o) {
+    if (order_descuento) {
+      int64_t gross = (int64_t)tot[o];
+      uint64_t disc;
+      if (descuento_mode == 0) {
+        disc = (uint64_t)(100 * (int64_t)order_descuento[o]);
+      } else {
+        __int128 x = (__int128)gross * (__int128)order_descuento[o];
+        __int128 r = x >= 0 ? (x + 50) / 100 : -((-x + 50) / 100);
+        disc = (uint64_t)r;                               /* low 64 bits: wrap-around */
+      }
+      tot[o] -= disc;
+    }
+    int32_t c = order_customer[o];
+    if (c < 0 || c >= n_customers) { flags |= 4; continue; }
+    if (!order_state || (order_state[o] & 1)) ct[c] += tot[o];
+  }
+  return flags;
+}
+
 /* ---------------- synthetic data (see include/acmpc.h for the recipe) -------- */
 
 #define GOLDEN 0x9E3779B97F4A7C15ull

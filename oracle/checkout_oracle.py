@@ -224,13 +224,23 @@ def columnar(store: Store, n_customers_dict: Optional[Dict[str, int]] = None):
 
 # ---- array-level oracle (pure Python loops; small inputs only) ------------------------------
 
-def aggregate_py(order_id, product_idx, qty, order_customer, order_id_base, n_customers, price_cents):
-    """Row-at-a-time integer-cent aggregate with Python ints reduced mod 2^64 at the end."""
+def aggregate_py(order_id, product_idx, qty, order_customer, order_id_base, n_customers, price_cents,
+                 line_price=None, order_state=None, order_descuento=None, descuento_mode=0):
+    """Row-at-a-time integer-cent aggregate with Python ints reduced mod 2^64.
+
+    The optional columns are the order lifecycle (definitions in include/acmpc.h): the price a line was
+    sold at (process/updateProduct.php:15 changes Precio later), whether the order still counts
+    (process/updatePedido.php:11, process/delPedido.php:12-13) and venta.Descuento (store.sql:162)."""
+    def wrap(v):
+        v &= (1 << 64) - 1
+        return v - (1 << 64) if v >= (1 << 63) else v
+
     m = len(order_customer)
     p_n = len(price_cents)
     tot = [0] * m
     pq = [0] * p_n
     ct = [0] * n_customers
+    counts = [True] * m if order_state is None else [bool(int(s) & 1) for s in order_state]
     for l in range(len(order_id)):
         o = int(order_id[l]) - order_id_base
         if o < 0 or o >= m:
@@ -239,14 +249,21 @@ def aggregate_py(order_id, product_idx, qty, order_customer, order_id_base, n_cu
         if p < 0 or p >= p_n:
             continue
         q = int(qty[l])
-        tot[o] += int(price_cents[p]) * q
-        pq[p] += q
+        price = int(price_cents[p]) if line_price is None else int(line_price[l])
+        tot[o] += price * q
+        if counts[o]:
+            pq[p] += q
     for o in range(m):
+        if order_descuento is not None:
+            gross = wrap(tot[o])
+            d = int(order_descuento[o])
+            if descuento_mode == 0:
+                disc = 100 * d
+            else:
+                x = gross * d
+                disc = (abs(x) + 50) // 100 * (1 if x >= 0 else -1)     # half away from zero
+            tot[o] = gross - disc
         c = int(order_customer[o])
-        if 0 <= c < n_customers:
-            ct[c] += tot[o]
-
-    def wrap(v):
-        v &= (1 << 64) - 1
-        return v - (1 << 64) if v >= (1 << 63) else v
+        if 0 <= c < n_customers and counts[o]:
+            ct[c] += wrap(tot[o])
     return [wrap(v) for v in tot], [wrap(v) for v in pq], [wrap(v) for v in ct]

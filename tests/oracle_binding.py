@@ -20,6 +20,8 @@ class Oracle:
         vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
         lib.oracle_aggregate.argtypes = [vp, vp, vp, i64, vp, i64, i32, i32, vp, i32, vp, vp, vp]
         lib.oracle_aggregate.restype = C.c_int
+        lib.oracle_aggregate_lifecycle.argtypes = [vp, vp, vp, i64, vp, i64, i32, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp]
+        lib.oracle_aggregate_lifecycle.restype = C.c_int
         lib.oracle_hash.argtypes = [C.c_uint64, C.c_uint64]
         lib.oracle_hash.restype = C.c_uint64
         lib.oracle_synth_n_orders.argtypes = [i64]
@@ -51,6 +53,26 @@ class Oracle:
                                           cust.ctypes.data, cust.size, int(order_id_base), int(n_customers),
                                           price.ctypes.data, price.size, tot.ctypes.data, pq.ctypes.data,
                                           ct.ctypes.data)
+        return tot, pq, ct, flags
+
+    def aggregate_lifecycle(self, order_id, product_idx, qty, order_customer, order_id_base, n_customers, price_cents,
+                            line_price=None, order_state=None, order_descuento=None, descuento_mode=0):
+        oid = np.ascontiguousarray(order_id, np.int32)
+        pidx = np.ascontiguousarray(product_idx, np.int32)
+        q = np.ascontiguousarray(qty, np.int32)
+        cust = np.ascontiguousarray(order_customer, np.int32)
+        price = np.ascontiguousarray(price_cents, np.int64)
+        lp = None if line_price is None else np.ascontiguousarray(line_price, np.int64)
+        st = None if order_state is None else np.ascontiguousarray(order_state, np.uint8)
+        de = None if order_descuento is None else np.ascontiguousarray(order_descuento, np.int32)
+        tot = np.empty(cust.size, np.int64)
+        pq = np.empty(price.size, np.int64)
+        ct = np.empty(int(n_customers), np.int64)
+        ptr = lambda a: None if a is None else a.ctypes.data
+        flags = self.lib.oracle_aggregate_lifecycle(oid.ctypes.data, pidx.ctypes.data, q.ctypes.data, oid.size,
+                                                    cust.ctypes.data, cust.size, int(order_id_base), int(n_customers),
+                                                    price.ctypes.data, price.size, ptr(lp), ptr(st), ptr(de),
+                                                    int(descuento_mode), tot.ctypes.data, pq.ctypes.data, ct.ctypes.data)
         return tot, pq, ct, flags
 
     def synth_prices(self, n_products):
