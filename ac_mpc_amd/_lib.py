@@ -26,7 +26,7 @@ ST_ORDER_RANGE, ST_ORDER_UNSORTED, ST_CUSTOMER_RANGE, ST_INGEST_MALFORMED, ST_IN
 ST_EMIT_CAPACITY = 32
 EMIT_SQL, EMIT_CSV = 0, 1
 ORDER_COUNTS, DESCUENTO_UNITS, DESCUENTO_PERCENT = 1, 0, 1
-OPT_LINE_ORDER, ORDER_GROUPED, ORDER_ANY = 1, 0, 1
+OPT_LINE_ORDER, ORDER_GROUPED, ORDER_ANY, ORDER_AUTO = 1, 0, 1, 2
 K_LINES, K_FIXUP, K_CUSTOMERS, K_CUSTMERGE, N_KERNELS = 0, 1, 2, 3, 4
 
 

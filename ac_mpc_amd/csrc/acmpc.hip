@@ -109,6 +109,26 @@ int fail(acmpc_ctx* ctx, int code, const char* fmt, ...) {
                   #call, hipGetErrorString(e_));                                               \
   } while (0)
 
+// Makes the context's device current for the duration of an entry point and puts the caller's device
+// back afterwards: the library must not change the calling thread's current device as a side effect.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  hipError_t enter(int dev) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e != hipSuccess) return e;
+    if (prev != dev) {
+      e = hipSetDevice(dev);
+      switched = e == hipSuccess;
+    }
+    return e;
+  }
+  ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
+#define ENTER_DEVICE(ctx)   \
+  DeviceScope device_scope_; \
+  HIPCHK(ctx, device_scope_.enter((ctx)->device))
+
 template <typename T>
 int ensure(acmpc_ctx* ctx, DevBuf<T>& b, size_t n, bool zero_new = false) {
   if (n == 0) n = 1;
@@ -293,7 +313,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
   if (!aligned16(d_order_id) || !aligned16(d_product_idx) || !aligned16(d_qty) ||
       !aligned16(d_order_customer) || !aligned16(d_tot))
     return fail(ctx, ACMPC_E_ALIGN, "device columns must be 16-byte aligned");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ENTER_DEVICE(ctx);
 
   const int32_t P = ctx->n_products;
   if (ctx->carry_dirty) { int rc = clear_carries(ctx, st); if (rc) return rc; }
@@ -345,6 +365,8 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.rec_id = ctx->d_rec_id.p; a.rec_sum = ctx->d_rec_sum.p; a.status = ctx->d_status;
     a.line_price = reinterpret_cast<const long long*>(d_line_price);
     a.price_in_lds = xpose_prices ? 0 : 1;
+    a.only_if_unsorted = 0;
+    a.totals_only = 0;
     a.order_state = d_state;
 
     ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
@@ -387,6 +409,30 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     HIPCHK(ctx, hipGetLastError());
     if (!lp.lds_tables) {
       hipLaunchKernelGGL(k_move_clear, dim3((P + 255) / 256), dim3(256), 0, st, ctx->d_prod_carry.p, d_pq, P);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    if (ctx->line_order == ACMPC_ORDER_AUTO) {
+      // If the grouped pass met descending ids its order totals are wrong (the stock deltas are not):
+      // zero them and redo them with the any-order kernel.  All three launches leave at once otherwise.
+      LinesPlan ap;
+      plan_lines(ctx, n_lines, &ap, false);
+      if (ap.lpl != 4) { const int keep = ctx->k1_lpl; ctx->k1_lpl = 4; plan_lines(ctx, n_lines, &ap, false); ctx->k1_lpl = keep; }
+      LinesArgs b = a;
+      b.n_tiles = ap.n_tiles; b.tiles_per_wave = ap.tiles_per_wave; b.tile_lines = ap.tile_lines;
+      b.price_in_lds = 1; b.only_if_unsorted = 1; b.totals_only = 1;
+      hipLaunchKernelGGL(k_zero_if_unsorted, dim3(ctx->n_cu * 4), dim3(256), 0, st, d_tot, n_orders, ctx->d_status);
+      HIPCHK(ctx, hipGetLastError());
+      const size_t tables = ap.lds_tables ? (size_t)ctx->p_pad * (ap.price32 ? 8 : 12) : 0;
+      if (life_lines) {
+        if (!ap.lds_tables) rc = launch_lines_any<int64_t, false, true>(ctx, ap, tables, b, st);
+        else if (ap.price32) rc = launch_lines_any<int32_t, true, true>(ctx, ap, tables, b, st);
+        else rc = launch_lines_any<int64_t, true, true>(ctx, ap, tables, b, st);
+      }
+      else if (!ap.lds_tables) rc = launch_lines_any<int64_t, false>(ctx, ap, tables, b, st);
+      else if (ap.price32) rc = launch_lines_any<int32_t, true>(ctx, ap, tables, b, st);
+      else rc = launch_lines_any<int64_t, true>(ctx, ap, tables, b, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_clear_unsorted, dim3(1), dim3(64), 0, st, ctx->d_status);
       HIPCHK(ctx, hipGetLastError());
     }
     if (d_desc) {                 // totals are final after k_fixup: take the discounts off
@@ -496,7 +542,8 @@ ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
   int n = 0;
   HIPCHK(nullptr, hipGetDeviceCount(&n));
   if (device >= n) return fail(nullptr, ACMPC_E_INVALID, "acmpc_init: device %d of %d", device, n);
-  HIPCHK(nullptr, hipSetDevice(device));
+  DeviceScope init_scope;
+  HIPCHK(nullptr, init_scope.enter(device));
   hipDeviceProp_t prop;
   HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -528,7 +575,8 @@ ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
 
 ACMPC_API void acmpc_destroy(acmpc_ctx* ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
+  DeviceScope destroy_scope;
+  (void)destroy_scope.enter(ctx->device);
   (void)hipDeviceSynchronize();
   release(ctx->d_price); release(ctx->d_prod_slab); release(ctx->d_prod_carry);
   release(ctx->d_rec_id); release(ctx->d_rec_sum); release(ctx->d_cust_slab); release(ctx->d_cust_carry);
@@ -548,7 +596,7 @@ ACMPC_API void acmpc_destroy(acmpc_ctx* ctx) {
 ACMPC_API int acmpc_set_products(acmpc_ctx* ctx, const int64_t* price_cents, int32_t n_products) {
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_set_products: null context");
   if (!price_cents || n_products <= 0) return fail(ctx, ACMPC_E_INVALID, "acmpc_set_products: empty product table");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ENTER_DEVICE(ctx);
   HIPCHK(ctx, hipDeviceSynchronize());          // nothing may still be reading the old table
   int rc = ensure(ctx, ctx->d_price, (size_t)n_products + 1);
   if (rc) return rc;
@@ -589,7 +637,7 @@ ACMPC_API int acmpc_aggregate_lifecycle_device(acmpc_ctx* ctx, const int32_t* d_
 
 ACMPC_API int acmpc_status(acmpc_ctx* ctx, void* hip_stream, uint32_t* flags) {
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_status: null context");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ENTER_DEVICE(ctx);
   hipStream_t st = (hipStream_t)hip_stream;
   uint32_t f = 0;
   HIPCHK(ctx, hipMemcpyAsync(&f, ctx->d_status, sizeof(f), hipMemcpyDeviceToHost, st));
@@ -627,7 +675,7 @@ ACMPC_API int acmpc_aggregate_lifecycle(acmpc_ctx* ctx, const int32_t* order_id,
   if ((n_lines > 0 && (!order_id || !product_idx || !qty)) || (n_orders > 0 && (!order_customer || !out_order_total_cents)) ||
       !out_product_qty || !out_customer_total_cents)
     return fail(ctx, ACMPC_E_INVALID, "null host pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ENTER_DEVICE(ctx);
   const int32_t P = ctx->n_products;
   int rc;
   if ((rc = ensure(ctx, ctx->s_order_id, (size_t)n_lines))) return rc;
@@ -678,7 +726,8 @@ ACMPC_API int acmpc_aggregate_lifecycle(acmpc_ctx* ctx, const int32_t* order_id,
 
 ACMPC_API int acmpc_set_option(acmpc_ctx* ctx, int option, int64_t value) {
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_set_option: null context");
-  if (option == ACMPC_OPT_LINE_ORDER && (value == ACMPC_ORDER_GROUPED || value == ACMPC_ORDER_ANY)) {
+  if (option == ACMPC_OPT_LINE_ORDER &&
+      (value == ACMPC_ORDER_GROUPED || value == ACMPC_ORDER_ANY || value == ACMPC_ORDER_AUTO)) {
     ctx->line_order = (int)value;
     return ACMPC_OK;
   }
@@ -696,7 +745,7 @@ ACMPC_API int acmpc_last_kernel_ms(acmpc_ctx* ctx, float* ms) {
   if (!ctx || !ms) return fail(ctx, ACMPC_E_INVALID, "acmpc_last_kernel_ms: null argument");
   if (!ctx->profiling || !ctx->ev_recorded)
     return fail(ctx, ACMPC_E_STATE, "no profiled acmpc_aggregate_device call to report");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ENTER_DEVICE(ctx);
   HIPCHK(ctx, hipEventSynchronize(ctx->ev[ACMPC_N_KERNELS]));
   for (int i = 0; i < ACMPC_N_KERNELS; ++i) HIPCHK(ctx, hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
   return ACMPC_OK;
@@ -741,7 +790,7 @@ ACMPC_API int acmpc_synth_generate_device(acmpc_ctx* ctx, const acmpc_synth_cfg*
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_synth_generate_device: null context");
   int rc = synth_check(ctx, cfg);
   if (rc) return rc;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ENTER_DEVICE(ctx);
   hipStream_t st = (hipStream_t)hip_stream;
   const int64_t M = synth_count_orders(cfg->n_lines_total);
   const int64_t lo = (int64_t)(((__int128)M * cfg->rank) / cfg->world);
@@ -782,7 +831,7 @@ ACMPC_API int acmpc_synth_generate_device(acmpc_ctx* ctx, const acmpc_synth_cfg*
 ACMPC_API int acmpc_set_product_codes(acmpc_ctx* ctx, const char* codes32, int32_t n_products) {
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_set_product_codes: null context");
   if (!codes32 || n_products <= 0) return fail(ctx, ACMPC_E_INVALID, "acmpc_set_product_codes: empty code list");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ENTER_DEVICE(ctx);
   HIPCHK(ctx, hipDeviceSynchronize());
   uint32_t size = 16;
   while (size < 2u * (uint32_t)n_products + 2u) size <<= 1;
@@ -838,7 +887,7 @@ ACMPC_API int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, in
   if (n_bytes > 0 && !d_text) return fail(ctx, ACMPC_E_INVALID, "null text pointer");
   if (capacity_rows > 0 && (!d_order_id || !d_product_idx || !d_qty)) return fail(ctx, ACMPC_E_INVALID, "null column pointer");
   if (!aligned16(d_text)) return fail(ctx, ACMPC_E_ALIGN, "device text must be 16-byte aligned");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ENTER_DEVICE(ctx);
   hipStream_t st = (hipStream_t)hip_stream;
   IngestArgs a;
   a.text = reinterpret_cast<const unsigned char*>(d_text);
@@ -877,7 +926,7 @@ ACMPC_API int acmpc_ingest_detalle(acmpc_ctx* ctx, const char* text, int64_t n_b
   if (n_bytes < 0 || capacity_rows < 0 || !n_rows || (n_bytes > 0 && !text))
     return fail(ctx, ACMPC_E_INVALID, "acmpc_ingest_detalle: bad argument");
   if (capacity_rows > 0 && (!order_id || !product_idx || !qty)) return fail(ctx, ACMPC_E_INVALID, "null column pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ENTER_DEVICE(ctx);
   int rc;
   if ((rc = ensure(ctx, ctx->s_text, (size_t)n_bytes + 16))) return rc;
   if ((rc = ensure(ctx, ctx->s_order_id, (size_t)capacity_rows))) return rc;
@@ -929,7 +978,7 @@ int emit_device_impl(acmpc_ctx* ctx, const char* who, int kind, const int64_t* d
   if (n_rows > 0 && !d_value) return fail(ctx, ACMPC_E_INVALID, "%s: null value pointer", who);
   if (capacity > 0 && !d_text) return fail(ctx, ACMPC_E_INVALID, "%s: null text pointer", who);
   if (!aligned16(d_text)) return fail(ctx, ACMPC_E_ALIGN, "%s: device text must be 16-byte aligned", who);
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ENTER_DEVICE(ctx);
   EmitArgs a;
   a.value = reinterpret_cast<const long long*>(d_value);
   a.n_rows = n_rows;
@@ -956,7 +1005,7 @@ int emit_host_impl(acmpc_ctx* ctx, const char* who, int kind, const int64_t* val
                    int style, char* text, int64_t capacity, int64_t* n_bytes) {
   if (!n_bytes || n_rows < 0 || capacity < 0 || (n_rows > 0 && !value) || (capacity > 0 && !text))
     return fail(ctx, ACMPC_E_INVALID, "%s: bad argument", who);
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ENTER_DEVICE(ctx);
   int rc;
   if ((rc = ensure(ctx, ctx->s_emit_value, (size_t)n_rows))) return rc;
   if ((rc = ensure(ctx, ctx->s_text, (size_t)capacity + 16))) return rc;

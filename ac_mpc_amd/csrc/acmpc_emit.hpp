@@ -241,22 +241,28 @@ struct ScanArgs {
 };
 
 __global__ void __launch_bounds__(1024) k_chunk_scan(ScanArgs a) {
+  constexpr int kStrip = 8;                     // consecutive values per thread and round
   __shared__ long long s_w[16];
   __shared__ long long s_carry;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_carry = 0;
   __syncthreads();
-  for (int64_t i0 = 0; i0 < a.n; i0 += 1024) {
-    const int64_t i = i0 + tid;
-    const long long v = i < a.n ? a.v[i] : 0;
-    long long incl = v;
+  for (int64_t i0 = 0; i0 < a.n; i0 += 1024 * kStrip) {
+    const int64_t i = i0 + (int64_t)tid * kStrip;
+    long long v[kStrip];
+    long long sum = 0;
+#pragma unroll
+    for (int k = 0; k < kStrip; ++k) { v[k] = i + k < a.n ? a.v[i + k] : 0; sum += v[k]; }
+    long long incl = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const long long t = __shfl_up(incl, d); if (lane >= d) incl += t; }
     if (lane == 63) s_w[wave] = incl;
     __syncthreads();
     long long off = s_carry;
     for (int k = 0; k < wave; ++k) off += s_w[k];
-    if (i < a.n) a.v[i] = off + incl - v;
+    long long run = off + incl - sum;
+#pragma unroll
+    for (int k = 0; k < kStrip; ++k) { if (i + k < a.n) a.v[i + k] = run; run += v[k]; }
     __syncthreads();
     if (tid == 1023) s_carry = off + incl;
     __syncthreads();

@@ -62,6 +62,10 @@ struct LinesArgs {
   // order lifecycle (kLife kernels only; each may be null)
   const long long* line_price;        // [n_lines] price at the time of sale, instead of the table
   int32_t price_in_lds;               // 0: no price table in LDS (line prices make it unnecessary)
+  // k_lines_any as the fallback of the grouped kernel: run only if the grouped pass found the ids
+  // unsorted, and redo the order totals only (stock deltas do not depend on the row order)
+  int32_t only_if_unsorted;
+  int32_t totals_only;
   const unsigned char* order_state;   // [M] bit 0: the order counts towards stock and customer sums
 };
 
@@ -529,6 +533,9 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
   const int wave = (int)(threadIdx.x >> 6);
   const int waves_per_block = (int)(blockDim.x >> 6);
   const uint32_t P = (uint32_t)a.n_products;
+  if (a.only_if_unsorted && !(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStUnsorted))
+    return;                                             // uniform: the whole grid leaves
+  const bool hist = !a.totals_only;
   const bool price_lds = !kLife || a.price_in_lds != 0;
   PriceT* s_price = reinterpret_cast<PriceT*>(smem);
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + (price_lds ? (size_t)a.p_pad * sizeof(PriceT) : 0));
@@ -585,11 +592,13 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
       const long long own = pi[i] < P ? sn[i] : 0ll;        // the line's own price (lifecycle)
       if (kLdsTables) {
         v[i] = (snapped ? own : (long long)s_price[price_lds ? pi[i] : 0]) * (long long)qs[i];
-        __hip_atomic_fetch_add(&s_hist[pi[i]], (uint32_t)qh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        qmax = max(qmax, (uint32_t)qh[i]);
+        if (hist) {
+          __hip_atomic_fetch_add(&s_hist[pi[i]], (uint32_t)qh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          qmax = max(qmax, (uint32_t)qh[i]);
+        }
       } else {
         v[i] = (snapped ? own : a.price[pi[i]]) * (long long)qs[i];
-        if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qh[i]);
+        if (hist && pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qh[i]);
       }
     }
     if (kLdsTables && qmax >= a.q_small) {
@@ -640,11 +649,21 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
     if (lane == kWave - 1) settle(pid, run);          // the tile's last run
   }
   if (st) atomicOr(a.status, st);
-  if (kLdsTables) {
+  if (kLdsTables && hist) {
     __syncthreads();
     uint32_t* slab = a.prod_slab + (size_t)blockIdx.x * a.p_pad;
     for (int i = (int)threadIdx.x; i < a.n_products; i += (int)blockDim.x) slab[i] = s_hist[i];
   }
+}
+
+// Fallback helpers: act only if the grouped pass raised kStUnsorted.
+__global__ void __launch_bounds__(256) k_zero_if_unsorted(int64_t* out, int64_t n, const uint32_t* status) {
+  if (!(__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStUnsorted)) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = 0;
+}
+
+__global__ void k_clear_unsorted(uint32_t* status) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) atomicAnd(status, ~kStUnsorted);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -165,12 +165,13 @@ class MotorLote:
         return int(flags.value)
 
     # -- options ------------------------------------------------------------------------------
-    def orden_lineas(self, cualquiera: bool) -> None:
+    def orden_lineas(self, cualquiera) -> None:
         """False (default): the `detalle` rows of an order are contiguous and order ids ascend, as
         process/confirmcompra.php:35-37 writes them.  True: no promise (concurrent checkouts interleave
-        rows); same results through a slower atomic path."""
-        self._check(self._lib.acmpc_set_option(self._ctx, _lib.OPT_LINE_ORDER,
-                                               _lib.ORDER_ANY if cualquiera else _lib.ORDER_GROUPED))
+        rows); same results through a slower atomic path.  "auto": the grouped pass first, and the
+        atomic path only if it met a descending order id (decided on the GPU)."""
+        modo = _lib.ORDER_AUTO if cualquiera == "auto" else _lib.ORDER_ANY if cualquiera else _lib.ORDER_GROUPED
+        self._check(self._lib.acmpc_set_option(self._ctx, _lib.OPT_LINE_ORDER, modo))
 
     # -- kernel timing --------------------------------------------------------------------------
     def perfilar(self, activo: bool) -> None:

@@ -33,6 +33,24 @@ class consultasLote {
                             int32_t order_id_base, int32_t n_customers,
                             int64_t* out_order_total_cents, int64_t* out_product_qty,
                             int64_t* out_customer_total_cents);
+        typedef struct acmpc_lifecycle {
+            const int64_t* line_price_cents; const uint8_t* order_state; const int32_t* order_descuento;
+            int32_t descuento_mode;
+        } acmpc_lifecycle;
+        int acmpc_aggregate_lifecycle(acmpc_ctx* ctx,
+                            const int32_t* order_id, const int32_t* product_idx, const int32_t* qty, int64_t n_lines,
+                            const int32_t* order_customer, int64_t n_orders,
+                            int32_t order_id_base, int32_t n_customers, const acmpc_lifecycle* life,
+                            int64_t* out_order_total_cents, int64_t* out_product_qty,
+                            int64_t* out_customer_total_cents);
+        int acmpc_set_product_codes(acmpc_ctx* ctx, const char* codes32, int32_t n_products);
+        int acmpc_ingest_detalle(acmpc_ctx* ctx, const char* text, int64_t n_bytes,
+                            int32_t* order_id, int32_t* product_idx, int32_t* qty,
+                            int64_t capacity_rows, int64_t* n_rows, int64_t* n_malformed);
+        int acmpc_emit_totals(acmpc_ctx* ctx, const int64_t* order_total_cents, int64_t n_orders,
+                            int32_t order_id_base, int style, char* text, int64_t capacity_bytes, int64_t* n_bytes);
+        int acmpc_emit_stock(acmpc_ctx* ctx, const int64_t* product_qty, int32_t n_products, int style,
+                            char* text, int64_t capacity_bytes, int64_t* n_bytes);
     ";
 
     /* Counterpart of ejecutarSQL::conectar() (library/consulSQL.php:5-16). */
@@ -89,6 +107,67 @@ class consultasLote {
         for ($i = 0; $i < self::$nProductos; $i++) $DeltaStock[] = $pq[$i];
         for ($i = 0; $i < $nClientes; $i++) $TotalCliente[] = $ct[$i];
         return [$TotalPagar, $DeltaStock, $TotalCliente];
+    }
+
+    /* CodigoProd of every product, in the order of CargarProductos (varchar(30), store.sql:110). */
+    public static function CargarCodigos($codigos) {
+        self::conectar();
+        $p = count($codigos);
+        $tabla = self::$ffi->new("char[" . max(32 * $p, 1) . "]");
+        FFI::memset($tabla, 0, max(32 * $p, 1));
+        for ($i = 0; $i < $p; $i++) {
+            $c = (string)$codigos[$i];
+            if (strlen($c) > 30) die("Problemas al cargar codigos: CodigoProd de mas de 30 bytes");
+            FFI::memcpy(FFI::addr($tabla[32 * $i]), $c, strlen($c));
+        }
+        self::comprobar(self::$ffi->acmpc_set_product_codes(self::$ctx, $tabla, $p), "cargar codigos");
+    }
+
+    /*
+     * Text of detalle rows (a dump in the style of store.sql:88-89, the statement of
+     * process/confirmcompra.php:36, or comma / tab separated rows) -> [NumPedido[], IndiceProd[], Cantidad[]].
+     */
+    public static function LeerDetalle($texto) {
+        self::conectar();
+        $cap = substr_count($texto, "\n") + 1;
+        $oid = self::$ffi->new("int32_t[$cap]");
+        $pid = self::$ffi->new("int32_t[$cap]");
+        $qty = self::$ffi->new("int32_t[$cap]");
+        $n = self::$ffi->new("int64_t");
+        $malas = self::$ffi->new("int64_t");
+        self::comprobar(self::$ffi->acmpc_ingest_detalle(self::$ctx, $texto, strlen($texto), $oid, $pid, $qty, $cap,
+                                                         FFI::addr($n), FFI::addr($malas)), "leer detalle");
+        $NumPedido = []; $IndiceProd = []; $Cantidad = [];
+        for ($i = 0; $i < $n->cdata; $i++) { $NumPedido[] = $oid[$i]; $IndiceProd[] = $pid[$i]; $Cantidad[] = $qty[$i]; }
+        return [$NumPedido, $IndiceProd, $Cantidad];
+    }
+
+    /*
+     * The statements consultasSQL::UpdateSQL would send (library/consulSQL.php:43-44), one per line:
+     * "update venta set TotalPagar='2200.00' where NumPedido='5';" for every order.
+     */
+    public static function SentenciasTotalPagar($TotalPagar, $primerPedido) {
+        self::conectar();
+        $m = count($TotalPagar);
+        $tot = self::columna("int64_t", $TotalPagar);
+        $cap = max(83 * $m, 1);
+        $out = self::$ffi->new("char[$cap]");
+        $len = self::$ffi->new("int64_t");
+        self::comprobar(self::$ffi->acmpc_emit_totals(self::$ctx, $tot, $m, $primerPedido, 0, $out, $cap, FFI::addr($len)),
+                        "escribir TotalPagar");
+        return FFI::string($out, $len->cdata);
+    }
+
+    /* "update producto set Stock=Stock-3 where CodigoProd='1';" for every product with a non-zero delta. */
+    public static function SentenciasStock($DeltaStock) {
+        self::conectar();
+        $p = count($DeltaStock);
+        $dq = self::columna("int64_t", $DeltaStock);
+        $cap = max(103 * $p, 1);
+        $out = self::$ffi->new("char[$cap]");
+        $len = self::$ffi->new("int64_t");
+        self::comprobar(self::$ffi->acmpc_emit_stock(self::$ctx, $dq, $p, 0, $out, $cap, FFI::addr($len)), "escribir Stock");
+        return FFI::string($out, $len->cdata);
     }
 
     public static function desconectar() {

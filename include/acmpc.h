@@ -206,11 +206,17 @@ int acmpc_status(acmpc_ctx* ctx, void* hip_stream, uint32_t* flags);
  *                                  (process/confirmcompra.php:27,35-37; `detalle` has no primary key,
  *                                  store.sql:192-194).  Same results, through 64-bit global atomics
  *                                  per run of equal ids: several times slower.
+ *   ACMPC_ORDER_AUTO               the grouped pass runs first; only if it meets a descending order id
+ *                                  are the order totals redone by the any-order pass (decided on the
+ *                                  device, without a host round trip).  Costs three near-empty kernel
+ *                                  launches when the rows were grouped after all.  An input that is
+ *                                  not non-decreasing contains a descent, so none slips through.
  * No counterpart in the reference, which never reads `detalle` back.
  */
 #define ACMPC_OPT_LINE_ORDER   1
 #define ACMPC_ORDER_GROUPED    0
 #define ACMPC_ORDER_ANY        1
+#define ACMPC_ORDER_AUTO       2
 int acmpc_set_option(acmpc_ctx* ctx, int option, int64_t value);
 
 /*

@@ -279,17 +279,18 @@ def test_full_size_100m_lines(motor, oracle, zipf):
 # ---- rows not grouped by order (concurrent checkouts interleave their detalle inserts) ------------
 
 def _check_any_order(motor, oracle, oid, pidx, qty, cust, base, c_n, price):
-    motor.orden_lineas(True)
-    try:
-        motor.cargar_productos(price)
-        tot, pq, ct = motor.agregar(oid, pidx, qty, cust, base, c_n)
-    finally:
-        motor.orden_lineas(False)
     etot, epq, ect, flags = oracle.aggregate(oid, pidx, qty, cust, base, c_n, price)
     assert flags & ~2 == 0                                  # the oracle only notes that ids are unsorted
-    np.testing.assert_array_equal(tot, etot)
-    np.testing.assert_array_equal(pq, epq)
-    np.testing.assert_array_equal(ct, ect)
+    for modo in (True, "auto"):
+        motor.orden_lineas(modo)
+        try:
+            motor.cargar_productos(price)
+            tot, pq, ct = motor.agregar(oid, pidx, qty, cust, base, c_n)
+        finally:
+            motor.orden_lineas(False)
+        np.testing.assert_array_equal(tot, etot)
+        np.testing.assert_array_equal(pq, epq)
+        np.testing.assert_array_equal(ct, ect)
 
 
 @pytest.mark.parametrize("n,p,c,mode", [(1000, 100, 50, "shuffle"), (300_003, 10_000, 100_000, "shuffle"),
@@ -326,3 +327,31 @@ def test_grouped_mode_still_rejects_shuffled_rows(motor, oracle):
     with pytest.raises(ErrorLote) as e:
         motor.agregar(d["order_id"][perm], d["product_idx"][perm], d["qty"][perm], d["order_customer"], 5, 50)
     assert e.value.code == _lib.E_DATA
+
+
+def test_auto_order_one_descent_in_a_large_input(motor, oracle):
+    """A single pair of swapped rows, far from any tile start, sends the totals through the fallback;
+    an id outside the order range is still reported."""
+    d = oracle.synth(3_000_000, 10_000, 100_000, qty_mode=1)
+    oid, pidx, qty = d["order_id"].copy(), d["product_idx"].copy(), d["qty"].copy()
+    k = 1_234_567
+    while oid[k] == oid[k + 1]:
+        k += 1
+    for col in (oid, pidx, qty):
+        col[k], col[k + 1] = col[k + 1], col[k]
+    price = oracle.synth_prices(10_000)
+    etot, epq, ect, flags = oracle.aggregate(oid, pidx, qty, d["order_customer"], 5, 100_000, price)
+    assert flags == 2
+    motor.cargar_productos(price)
+    motor.orden_lineas("auto")
+    try:
+        tot, pq, ct = motor.agregar(oid, pidx, qty, d["order_customer"], 5, 100_000)
+        np.testing.assert_array_equal(tot, etot)
+        np.testing.assert_array_equal(pq, epq)
+        np.testing.assert_array_equal(ct, ect)
+        oid[77] = 4                                           # below the base
+        with pytest.raises(ErrorLote) as e:
+            motor.agregar(oid, pidx, qty, d["order_customer"], 5, 100_000)
+        assert e.value.code == _lib.E_DATA
+    finally:
+        motor.orden_lineas(False)
