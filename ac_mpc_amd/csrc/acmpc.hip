@@ -81,6 +81,7 @@ struct acmpc_ctx {
   int k1_blocks_per_cu = 1;
   int k1_lpl = 4;
   int k2_threads = 1024;
+  int k1_cus = 0, k2_cus = 0;   // developer switches: pretend the device has this many CUs (0 = all)
   int force_global_tables = 0;
   int line_order = ACMPC_ORDER_GROUPED;
 
@@ -201,7 +202,7 @@ int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p, bool line_pr
     bpc = std::max(1, std::min(bpc, fit));
   }
   bpc = std::max(1, std::min(bpc, 2048 / p->threads));
-  int max_blocks = ctx->n_cu * bpc;
+  int max_blocks = (ctx->k1_cus > 0 ? std::min(ctx->k1_cus, ctx->n_cu) : ctx->n_cu) * bpc;
   max_blocks = std::min(max_blocks, kMaxWavesTotal / p->waves_per_block);
   p->n_tiles = (n_lines + p->tile_lines - 1) / p->tile_lines;
   const int64_t max_waves = (int64_t)max_blocks * p->waves_per_block;
@@ -221,7 +222,8 @@ struct CustPlan {
 
 void plan_customers(const acmpc_ctx* ctx, int64_t n_orders, int32_t n_customers, CustPlan* p) {
   p->threads = ctx->k2_threads;
-  const int slots = std::max(1, ctx->n_cu / 8);             // workgroups per XCD label, one per CU
+  const int cus = ctx->k2_cus > 0 ? std::min(ctx->k2_cus, ctx->n_cu) : ctx->n_cu;
+  const int slots = std::max(1, cus / 8);                   // workgroups per XCD label, one per CU
   // Every sibling workgroup of a stream re-reads the stream's orders through L2, so the number of
   // customer ranges R is kept as small as the LDS allows: 32-bit partial sums, one workgroup's LDS.
   const int64_t max_span = ((int64_t)kMaxLds - kLdsReserve - kWave * 4) / 4;
@@ -559,6 +561,8 @@ ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
   ctx->k1_blocks_per_cu = std::max(1, env_int("ACMPC_K1_BPC", 1));
   ctx->k1_lpl = env_int("ACMPC_K1_LPL", 4);
   ctx->k2_threads = env_int("ACMPC_K2_THREADS", 1024);
+  ctx->k1_cus = env_int("ACMPC_K1_CUS", 0);
+  ctx->k2_cus = env_int("ACMPC_K2_CUS", 0);
   if (ctx->k2_threads != 256 && ctx->k2_threads != 512 && ctx->k2_threads != 1024) ctx->k2_threads = 1024;
   ctx->force_global_tables = env_int("ACMPC_FORCE_GLOBAL_TABLES", 0);
   hipError_t e = hipMalloc((void**)&ctx->d_status, sizeof(uint32_t));

@@ -44,7 +44,9 @@ def build_library(force: bool = False) -> str:
 
 def build_oracle(force: bool = False) -> str:
     if force or not _newer(ORACLE_LIB, [os.path.join(ORACLE_DIR, "aggregate_oracle.c"),
-                                        os.path.join(ORACLE_DIR, "ingest_oracle.c")]):
+                                        os.path.join(ORACLE_DIR, "ingest_oracle.c"),
+                                        os.path.join(ORACLE_DIR, "emit_oracle.c"),
+                                        os.path.join(ORACLE_DIR, "Makefile")]):
         _run(["make", "-C", ORACLE_DIR, "-B", "liboracle.so"])
     return ORACLE_LIB
 

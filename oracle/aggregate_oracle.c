@@ -35,6 +35,7 @@
  * Sums are kept in uint64_t so that overflow wraps (two's complement) instead
  * of being undefined; results are reinterpreted as int64_t.
  */
+#define _POSIX_C_SOURCE 200809L      /* pthread barriers under -std=c11 */
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -136,6 +137,115 @@ ORACLE_API int oracle_aggregate_lifecycle(const int32_t* order_id, const int32_t
     if (c < 0 || c >= n_customers) { flags |= 4; continue; }
     if (!order_state || (order_state[o] & 1)) ct[c] += tot[o];
   }
+  return flags;
+}
+
+/*
+ * oracle_aggregate on n_threads host threads: the orders are cut into n_threads contiguous ranges on
+ * order boundaries (the same cut the multi-GPU path makes), every thread walks the lines of its
+ * range with private per-product and per-customer sums, and the private sums are added up at the end.
+ * Requires non-decreasing order ids (a descent found by any thread sends the whole call to the
+ * one-thread walk).
+ * Integer sums: the result is identical to the one-thread walk.
+ */
+#include <pthread.h>
+
+typedef struct {
+  const int32_t *order_id, *product_idx, *qty, *order_customer;
+  int64_t line_lo, line_hi, order_lo, order_hi, n_orders;
+  int32_t base, n_customers, n_products;
+  const int64_t* price;
+  uint64_t *tot, *pq, *ct;       /* tot: shared (disjoint ranges); pq, ct: private */
+  /* second phase: every thread adds up one slice of the private sums of all threads */
+  uint64_t *scratch, *out_pq, *out_ct;
+  size_t priv;
+  int t, n_threads;
+  pthread_barrier_t* barrier;
+  int flags;
+} mt_job;
+
+static void* mt_worker(void* arg)
+{
+  mt_job* j = (mt_job*)arg;
+  memset(j->pq, 0, j->priv * sizeof(uint64_t));
+  memset(j->tot + j->order_lo, 0, (size_t)(j->order_hi - j->order_lo) * sizeof(uint64_t));
+  for (int64_t l = j->line_lo; l < j->line_hi; ++l) {
+    if (l > 0 && j->order_id[l] < j->order_id[l - 1]) { j->flags |= 2; break; }   /* redone on one thread */
+    int64_t o = (int64_t)j->order_id[l] - (int64_t)j->base;
+    if (o < 0 || o >= j->n_orders) { j->flags |= 1; continue; }
+    int32_t p = j->product_idx[l];
+    if (p < 0 || p >= j->n_products) continue;
+    uint64_t q = (uint64_t)(int64_t)j->qty[l];
+    j->tot[o] += (uint64_t)j->price[p] * q;
+    j->pq[p] += q;
+  }
+  if (!(j->flags & 2)) {
+    for (int64_t o = j->order_lo; o < j->order_hi; ++o) {
+      int32_t c = j->order_customer[o];
+      if (c < 0 || c >= j->n_customers) { j->flags |= 4; continue; }
+      j->ct[c] += j->tot[o];
+    }
+  }
+  pthread_barrier_wait(j->barrier);
+  /* slice [lo, hi) of the concatenated [product | customer] sums */
+  size_t lo = j->priv * (size_t)j->t / (size_t)j->n_threads, hi = j->priv * (size_t)(j->t + 1) / (size_t)j->n_threads;
+  for (size_t i = lo; i < hi; ++i) {
+    uint64_t acc = 0;
+    for (int t = 0; t < j->n_threads; ++t) acc += j->scratch[j->priv * (size_t)t + i];
+    if (i < (size_t)j->n_products) j->out_pq[i] = acc; else j->out_ct[i - (size_t)j->n_products] = acc;
+  }
+  return NULL;
+}
+
+ORACLE_API int oracle_aggregate_mt(const int32_t* order_id, const int32_t* product_idx,
+                                   const int32_t* qty, int64_t n_lines,
+                                   const int32_t* order_customer, int64_t n_orders,
+                                   int32_t order_id_base, int32_t n_customers,
+                                   const int64_t* price_cents, int32_t n_products,
+                                   int64_t* order_total_cents, int64_t* product_qty,
+                                   int64_t* customer_total_cents, int32_t n_threads)
+{
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  uint64_t* tot = (uint64_t*)order_total_cents;
+  size_t priv = (size_t)n_products + (size_t)n_customers;
+  uint64_t* scratch = (uint64_t*)malloc(priv * (size_t)n_threads * sizeof(uint64_t));
+  mt_job* jobs = (mt_job*)calloc((size_t)n_threads, sizeof(mt_job));
+  pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+  pthread_barrier_t barrier;
+  pthread_barrier_init(&barrier, NULL, (unsigned)n_threads);
+  int64_t line = 0;
+  for (int t = 0; t < n_threads; ++t) {
+    mt_job* j = &jobs[t];
+    j->order_id = order_id; j->product_idx = product_idx; j->qty = qty; j->order_customer = order_customer;
+    j->order_lo = n_orders * t / n_threads;
+    j->order_hi = n_orders * (t + 1) / n_threads;
+    j->n_orders = n_orders; j->base = order_id_base; j->n_customers = n_customers; j->n_products = n_products;
+    j->price = price_cents; j->tot = tot;
+    j->pq = scratch + priv * (size_t)t;
+    j->ct = j->pq + n_products;
+    j->scratch = scratch; j->priv = priv; j->t = t; j->n_threads = n_threads; j->barrier = &barrier;
+    j->out_pq = (uint64_t*)product_qty; j->out_ct = (uint64_t*)customer_total_cents;
+    /* lines of this range: ids below base + order_hi (the last thread also takes any id beyond the range;
+     * an id below the base lands in thread 0; both are flagged by the walk) */
+    j->line_lo = line;
+    if (t == n_threads - 1) line = n_lines;
+    else {
+      int64_t lo = line, hi = n_lines, key = (int64_t)order_id_base + j->order_hi;
+      while (lo < hi) { int64_t mid = lo + (hi - lo) / 2; if ((int64_t)order_id[mid] < key) lo = mid + 1; else hi = mid; }
+      line = lo;
+    }
+    j->line_hi = line;
+  }
+  for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+  int flags = 0;
+  for (int t = 0; t < n_threads; ++t) { pthread_join(th[t], NULL); flags |= jobs[t].flags; }
+  pthread_barrier_destroy(&barrier);
+  free(th); free(jobs); free(scratch);
+  if (flags & 2)                 /* the cut needs sorted ids: walk the table on one thread instead */
+    return oracle_aggregate(order_id, product_idx, qty, n_lines, order_customer, n_orders, order_id_base,
+                            n_customers, price_cents, n_products, order_total_cents, product_qty,
+                            customer_total_cents);
   return flags;
 }
 
