@@ -65,9 +65,12 @@ struct acmpc_ctx {
   // text ingest: dictionary of the product codes, chunk row counts, scalars, staging
   int32_t dict_products = 0;
   uint32_t dict_mask = 0;
-  DevBuf<unsigned long long> d_dict_hash, d_codes;
-  DevBuf<int32_t> d_dict_idx;
+  DevBuf<IngSlot> d_dict;
+  DevBuf<unsigned short> d_dict_disp;
+  uint32_t dict_seed = 0, dict_bucket_shift = 0;
+  DevBuf<unsigned long long> d_codes;
   DevBuf<long long> d_chunk_rows;
+  DevBuf<unsigned long long> d_ing_tables;   // row automaton: transition entries, then the byte classes
   long long* d_ing_scalars = nullptr;      // [0] rows found, [1] malformed rows
   DevBuf<unsigned char> s_text;
   int32_t code_sql_bad = -1, code_csv_bad = -1;   // first code a text style cannot carry, or -1
@@ -587,7 +590,7 @@ ACMPC_API void acmpc_destroy(acmpc_ctx* ctx) {
   release(ctx->s_order_id); release(ctx->s_product_idx); release(ctx->s_qty); release(ctx->s_order_customer);
   release(ctx->s_order_total); release(ctx->s_product_qty); release(ctx->s_customer_total);
   release(ctx->s_synth_off); release(ctx->s_synth_cdf);
-  release(ctx->d_dict_hash); release(ctx->d_codes); release(ctx->d_dict_idx); release(ctx->d_chunk_rows);
+  release(ctx->d_dict); release(ctx->d_dict_disp); release(ctx->d_codes); release(ctx->d_chunk_rows); release(ctx->d_ing_tables);
   release(ctx->s_text); release(ctx->d_chunk_bytes); release(ctx->s_emit_value);
   release(ctx->s_line_price); release(ctx->s_order_state); release(ctx->s_order_descuento);
   if (ctx->d_ing_scalars) (void)hipFree(ctx->d_ing_scalars);
@@ -839,8 +842,7 @@ ACMPC_API int acmpc_set_product_codes(acmpc_ctx* ctx, const char* codes32, int32
   HIPCHK(ctx, hipDeviceSynchronize());
   uint32_t size = 16;
   while (size < 2u * (uint32_t)n_products + 2u) size <<= 1;
-  std::vector<unsigned long long> hash(size, 0ull), codes((size_t)n_products * 4, 0ull);
-  std::vector<int32_t> idx(size, -1);
+  std::vector<unsigned long long> codes((size_t)n_products * 4, 0ull);
   int32_t sql_bad = -1, csv_bad = -1;
   for (int32_t i = 0; i < n_products; ++i) {
     const char* c = codes32 + (size_t)i * 32;
@@ -855,27 +857,94 @@ ACMPC_API int acmpc_set_product_codes(acmpc_ctx* ctx, const char* codes32, int32
     }
     for (size_t k = 0; k < len; ++k)
       codes[(size_t)i * 4 + (k >> 3)] |= (unsigned long long)(unsigned char)c[k] << (8 * (k & 7));
-    const unsigned long long kw[4] = {codes[(size_t)i * 4], codes[(size_t)i * 4 + 1], codes[(size_t)i * 4 + 2],
-                                      codes[(size_t)i * 4 + 3]};
-    const unsigned long long h = ing_code_hash(kw);
-    uint32_t s = (uint32_t)h & (size - 1);
-    while (idx[s] >= 0) {
-      if (hash[s] == h && memcmp(&codes[(size_t)idx[s] * 4], &codes[(size_t)i * 4], 32) == 0)
-        return fail(ctx, ACMPC_E_INVALID, "product codes %d and %d are equal (CodigoProd is a primary key, store.sql:200)", idx[s], i);
-      s = (s + 1) & (size - 1);
-    }
-    idx[s] = i;
-    hash[s] = h;
   }
+  {
+    // CodigoProd is a primary key (store.sql:200): equal codes are refused
+    std::vector<int32_t> order((size_t)n_products);
+    for (int32_t i = 0; i < n_products; ++i) order[(size_t)i] = i;
+    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+      const int c = memcmp(&codes[(size_t)x * 4], &codes[(size_t)y * 4], 32);
+      return c != 0 ? c < 0 : x < y;
+    });
+    for (int32_t i = 1; i < n_products; ++i)
+      if (memcmp(&codes[(size_t)order[(size_t)i - 1] * 4], &codes[(size_t)order[(size_t)i] * 4], 32) == 0)
+        return fail(ctx, ACMPC_E_INVALID, "product codes %d and %d are equal (CodigoProd is a primary key, store.sql:200)",
+                    order[(size_t)i - 1], order[(size_t)i]);
+  }
+  // Perfect hash by hash-and-displace: buckets (about four codes each) are placed largest first; a bucket's
+  // displacement is the first d that sends all its codes to distinct free slots.  A seed that cannot be
+  // completed (two codes with equal hash pairs) is replaced by the next one.
+  uint32_t n_buckets = 2;
+  while (n_buckets * 4u < (uint32_t)n_products) n_buckets <<= 1;
+  uint32_t bucket_bits = 0;
+  while ((1u << bucket_bits) < n_buckets) ++bucket_bits;
+  const uint32_t bucket_shift = 32u - bucket_bits;
+  IngSlot empty_slot;
+  memset(&empty_slot, 0, sizeof(empty_slot));
+  empty_slot.idx = -1;
+  std::vector<IngSlot> dict;
+  std::vector<unsigned short> disp;
+  uint32_t seed = 0;
+  bool built = false;
+  for (; seed < 16 && !built; ++seed) {
+    dict.assign(size, empty_slot);
+    disp.assign(n_buckets, 0);
+    std::vector<IngHash> hs((size_t)n_products);
+    std::vector<std::vector<int32_t>> members(n_buckets);
+    for (int32_t i = 0; i < n_products; ++i) {
+      uint32_t kw[8];
+      memcpy(kw, &codes[(size_t)i * 4], 32);         // little-endian host: the same eight words the kernel builds
+      hs[(size_t)i] = ing_code_hash(kw, seed);
+      members[hs[(size_t)i].a >> bucket_shift].push_back(i);
+    }
+    std::vector<uint32_t> by_size(n_buckets);
+    for (uint32_t b = 0; b < n_buckets; ++b) by_size[b] = b;
+    std::sort(by_size.begin(), by_size.end(), [&](uint32_t x, uint32_t y) {
+      return members[x].size() != members[y].size() ? members[x].size() > members[y].size() : x < y;
+    });
+    built = true;
+    std::vector<uint32_t> slots;
+    for (uint32_t bi = 0; bi < n_buckets && built; ++bi) {
+      const std::vector<int32_t>& m = members[by_size[bi]];
+      if (m.empty()) break;
+      uint32_t d = 0;
+      for (; d < 65536; ++d) {
+        slots.clear();
+        bool fits = true;
+        for (int32_t i : m) {
+          const uint32_t s = ing_slot_of(hs[(size_t)i], d, size - 1);
+          if (dict[s].idx >= 0 || std::find(slots.begin(), slots.end(), s) != slots.end()) { fits = false; break; }
+          slots.push_back(s);
+        }
+        if (fits) break;
+      }
+      if (d == 65536) { built = false; break; }
+      disp[by_size[bi]] = (unsigned short)d;
+      for (size_t k = 0; k < m.size(); ++k) {
+        dict[slots[k]].idx = m[k];
+        memcpy(dict[slots[k]].w, &codes[(size_t)m[k] * 4], 32);
+      }
+    }
+    if (built) break;
+  }
+  if (!built) return fail(ctx, ACMPC_E_INVALID, "could not index the product codes (hash construction failed for 16 seeds)");
   int rc;
-  if ((rc = ensure(ctx, ctx->d_dict_hash, size))) return rc;
-  if ((rc = ensure(ctx, ctx->d_dict_idx, size))) return rc;
+  if ((rc = ensure(ctx, ctx->d_dict, size))) return rc;
+  if ((rc = ensure(ctx, ctx->d_dict_disp, n_buckets))) return rc;
+  HIPCHK(ctx, hipMemcpy(ctx->d_dict_disp.p, disp.data(), (size_t)n_buckets * 2, hipMemcpyHostToDevice));
   if ((rc = ensure(ctx, ctx->d_codes, codes.size()))) return rc;
-  HIPCHK(ctx, hipMemcpy(ctx->d_dict_hash.p, hash.data(), (size_t)size * 8, hipMemcpyHostToDevice));
-  HIPCHK(ctx, hipMemcpy(ctx->d_dict_idx.p, idx.data(), (size_t)size * 4, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ctx->d_dict.p, dict.data(), (size_t)size * sizeof(IngSlot), hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(ctx->d_codes.p, codes.data(), codes.size() * 8, hipMemcpyHostToDevice));
   if (!ctx->d_ing_scalars) HIPCHK(ctx, hipMalloc((void**)&ctx->d_ing_scalars, 2 * sizeof(long long)));
+  if (!ctx->d_ing_tables.p) {
+    std::vector<unsigned long long> tab(kIngTableWords + 256 / 8, 0ull);
+    ing_build_tables(tab.data(), reinterpret_cast<unsigned char*>(tab.data() + kIngTableWords));
+    if ((rc = ensure(ctx, ctx->d_ing_tables, tab.size()))) return rc;
+    HIPCHK(ctx, hipMemcpy(ctx->d_ing_tables.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+  }
   ctx->dict_mask = size - 1;
+  ctx->dict_seed = seed;
+  ctx->dict_bucket_shift = bucket_shift;
   ctx->dict_products = n_products;
   ctx->code_sql_bad = sql_bad;
   ctx->code_csv_bad = csv_bad;
@@ -900,8 +969,11 @@ ACMPC_API int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, in
   int rc;
   if ((rc = ensure(ctx, ctx->d_chunk_rows, (size_t)a.n_chunks + 1))) return rc;
   a.chunk_rows = ctx->d_chunk_rows.p;
-  a.dict_hash = ctx->d_dict_hash.p; a.dict_idx = ctx->d_dict_idx.p; a.dict_mask = ctx->dict_mask;
+  a.dict = ctx->d_dict.p; a.dict_disp = ctx->d_dict_disp.p; a.dict_mask = ctx->dict_mask;
+  a.dict_seed = ctx->dict_seed; a.dict_bucket_shift = ctx->dict_bucket_shift;
   a.codes = ctx->d_codes.p;
+  a.tables = ctx->d_ing_tables.p;
+  a.ablate = env_int("ACMPC_ING_ABLATE", 0);
   a.order_id = d_order_id; a.product_idx = d_product_idx; a.qty = d_qty; a.capacity = capacity_rows;
   a.n_rows = reinterpret_cast<long long*>(d_n_rows);
   a.n_malformed = reinterpret_cast<unsigned long long*>(ctx->d_ing_scalars + 1);

@@ -8,10 +8,11 @@
 //
 // Two passes over the text (byte work, HBM-bandwidth bound; no MFMA):
 //   k_ingest_count   every 16 KiB chunk counts the data rows that START in it
-//   k_ingest_scan    exclusive prefix of the chunk counts (one workgroup)
+//   k_chunk_scan     exclusive prefix of the chunk counts (one workgroup)
 //   k_ingest_parse   every chunk is staged in LDS (plus 128 bytes of lookahead); each thread finds
-//                    the row starts in its 64 bytes, ranks them with a block scan, parses them from
-//                    LDS, looks the product code up in a hash dictionary and writes the columns
+//                    the row starts in its 64 bytes and ranks them with a block scan; the rows are
+//                    then handed out one per thread, run through a table-driven automaton, converted,
+//                    looked up in a hash dictionary of the product codes and written as columns
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,15 +26,18 @@ constexpr int kIngLook = 128;                           // lookahead kept in LDS
 constexpr int kIngMaxRow = 120;
 constexpr uint32_t kStIngestMalformed = 8u, kStIngestCapacity = 16u;
 
+struct IngSlot;
+
 struct IngestArgs {
   const unsigned char* text;
   int64_t n_bytes;
   int64_t n_chunks;
   long long* chunk_rows;              // [n_chunks + 1]: counts, then exclusive offsets; last = total
-  const unsigned long long* dict_hash;   // open-addressing dictionary of the product codes
-  const int32_t* dict_idx;               // -1 = empty slot
-  uint32_t dict_mask;
-  const unsigned long long* codes;    // [P][4]: the codes, 32 bytes each, NUL padded
+  const IngSlot* dict;            // perfect-hash dictionary of the product codes: one slot per probe
+  const unsigned short* dict_disp;       // displacement of every bucket
+  uint32_t dict_mask, dict_seed, dict_bucket_shift;
+  const unsigned long long* codes;    // [P][4]: the codes, 32 bytes each, NUL padded (emit kernels)
+  const unsigned long long* tables;   // automaton: kIngTableWords 64-bit entries, then the 256 byte classes
   int32_t* order_id;
   int32_t* product_idx;
   int32_t* qty;
@@ -41,6 +45,7 @@ struct IngestArgs {
   long long* n_rows;                  // device scalar: data rows found
   unsigned long long* n_malformed;    // device scalar
   uint32_t* status;
+  int32_t ablate;                     // developer switch for timing experiments (0 in production)
 };
 
 __device__ __forceinline__ bool ing_digit(uint32_t c) { return c - '0' < 10u; }
@@ -53,7 +58,7 @@ __device__ __forceinline__ bool ing_data_row(uint32_t c0, uint32_t c1) {
 // Bit 7 of every byte of w that equals '\n'.
 __device__ __forceinline__ uint32_t ing_newlines(uint32_t w) {
   const uint32_t x = w ^ 0x0A0A0A0Au;
-  return (x - 0x01010101u) & ~x & 0x80808080u;
+  return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;    // exact per byte: no borrow between bytes
 }
 
 // Calls f(offset) for every data-row start among the 64 text bytes held in w[16] (offset 0..63 is
@@ -147,114 +152,265 @@ __global__ void __launch_bounds__(kIngThreads) k_ingest_count(IngestArgs a) {
   }
 }
 
-// Hash of a product code given as its 32 NUL-padded bytes in four little-endian 64-bit words.
-__host__ __device__ __forceinline__ unsigned long long ing_code_hash(const unsigned long long (&k)[4]) {
-  unsigned long long h = k[0] * 0x9E3779B97F4A7C15ull;
-  h = (h ^ (h >> 29) ^ k[1]) * 0xBF58476D1CE4E5B9ull;
-  h = (h ^ (h >> 32) ^ k[2]) * 0x94D049BB133111EBull;
-  h = (h ^ (h >> 29) ^ k[3]) * 0x9E3779B97F4A7C15ull;
-  return h ^ (h >> 31);
+// Two hashes of a product code given as its 32 NUL-padded bytes in eight little-endian 32-bit words.
+// `a` is a seeded multiplicative chain over the words, `b` an independent rotation fold; the dictionary
+// is a perfect hash built on them (hash-and-displace): bucket = top bits of a, and every bucket has a
+// displacement d such that slot = (a + d * (b | 1)) & mask is a slot of its own for each of its codes.
+struct IngHash { uint32_t a, b; };
+__host__ __device__ __forceinline__ uint32_t ing_rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__host__ __device__ __forceinline__ IngHash ing_code_hash(const uint32_t (&w)[8], uint32_t seed) {
+  uint32_t a = 0x811C9DC5u ^ seed;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a = (a ^ w[i]) * 0x01000193u;
+  a ^= a >> 15;
+  a *= 0x85EBCA77u;
+  a ^= a >> 13;
+  uint32_t b = w[0] ^ ing_rotl(w[1], 5) ^ ing_rotl(w[2], 11) ^ ing_rotl(w[3], 17) ^ ing_rotl(w[4], 23) ^
+               ing_rotl(w[5], 29) ^ ing_rotl(w[6], 3) ^ ing_rotl(w[7], 9) ^ (seed * 0x9E3779B1u);
+  b *= 0x9E3779B1u;
+  b ^= b >> 16;
+  IngHash h;
+  h.a = a;
+  h.b = b;
+  return h;
+}
+__host__ __device__ __forceinline__ uint32_t ing_slot_of(IngHash h, uint32_t disp, uint32_t mask) {
+  return (h.a + disp * (h.b | 1u)) & mask;
 }
 
-// Parser state over the LDS copy of the text.  The staging code writes a '\n' right after the last
-// staged byte, and the parser never moves past a '\n', so no bounds check is needed per byte.
-struct IngCursor {
-  const unsigned char* s;
-  int p;
-  __device__ __forceinline__ uint32_t peek() const { return (uint32_t)s[p]; }
+// One dictionary slot: the code's eight words and the product index (-1 = empty slot), padded to 64
+// bytes so that a lookup (three independent 16-byte loads) stays inside one 64-byte piece of a cache line.
+struct alignas(64) IngSlot {
+  uint32_t w[8];
+  int32_t idx;
+  int32_t pad[7];
 };
 
-__device__ __forceinline__ void ing_skip_sp(IngCursor& c) { while (c.peek() == ' ') ++c.p; }
+// ---------------------------------------------------------------------------------------------
+// The row grammar as a table-driven automaton.
+//
+// A row is consumed one byte per step: class of the byte (13 classes) x state (33 states) -> one 64-bit
+// table entry holding the next state and two words of packed increments.  Summed over the row, the
+// increments give everything the parser needs to pick the fields out of the text afterwards —
+//   word A: digits of the first int, digits of the second int, code bytes, minus signs, row length
+//   word B: bytes up to the end of the first int's digits, bytes before the first code byte,
+//           bytes up to the end of the second int's digits
+// (7 bits each: a row is cut off after 128 bytes, and a field can only reach 128 in a row that never
+// arrives at the final state).  The numbers are then converted from their digits with a few
+// word-wide operations, the code is cut out with byte-aligned word reads.  No per-byte branches.
+// ---------------------------------------------------------------------------------------------
+enum : int {
+  kcDig, kcQ1, kcQ2, kcMinus, kcSp, kcComma, kcTab, kcSemi, kcRpar, kcLpar, kcCr, kcNl, kcOther, kNumClasses = 16
+};
+enum : int {
+  sStart, sASp, sAQ1, sAQ2, sANeg, sANegQ1, sANegQ2, sADig, sADigQ1, sADigQ2, sAEnd, sBSp, sCQ1, sCQ2, sCQEnd1,
+  sCQEnd2, sCBare, sCEnd, sDSp, sDQ1, sDQ2, sDNeg, sDNegQ1, sDNegQ2, sDDig, sDDigQ1, sDDigQ2, sESp, sEPar, sETerm,
+  sECr, sDone, sErr, kNumStates
+};
+constexpr int kIngTableWords = kNumStates * kNumClasses;     // 64-bit entries
+constexpr int kIngSteps = 128;                               // bytes of a row the automaton looks at
+constexpr int kIngFront = 16;                                // LDS bytes kept in front of the chunk
 
-__device__ __forceinline__ bool ing_int(IngCursor& c, int32_t& out) {
-  uint32_t q = 0;
-  uint32_t ch = c.peek();
-  if (ch == '\'' || ch == '"') { q = ch; ++c.p; ch = c.peek(); }
-  bool neg = false;
-  if (ch == '-') { neg = true; ++c.p; ch = c.peek(); }
-  int nd = 0;
-  long long v = 0;
-  while (ing_digit(ch)) {
-    v = v * 10 + (long long)(ch - '0');
-    ++c.p;
-    if (++nd > 10) return false;
-    ch = c.peek();
+// word A fields
+constexpr int kANd1 = 0, kANd2 = 7, kACl = 14, kANeg1 = 21, kANeg2 = 22, kALen = 23;
+// word B fields (bits 21..31 of the entry's low word hold 16 * next state)
+constexpr int kBE1 = 0, kBCs = 7, kBE2 = 14, kBState = 21;
+
+inline int ing_class_of(int c) {
+  if (c >= '0' && c <= '9') return kcDig;
+  switch (c) {
+    case '\'': return kcQ1;
+    case '"': return kcQ2;
+    case '-': return kcMinus;
+    case ' ': return kcSp;
+    case ',': return kcComma;
+    case '\t': return kcTab;
+    case ';': return kcSemi;
+    case ')': return kcRpar;
+    case '(': return kcLpar;
+    case '\r': return kcCr;
+    case '\n': return kcNl;
+    default: return kcOther;
   }
-  if (nd == 0) return false;
-  if (neg) v = -v;
-  if (v < -2147483648ll || v > 2147483647ll) return false;
-  if (q) { if (ch != q) return false; ++c.p; }
-  out = (int32_t)v;
-  return true;
 }
 
-__device__ __forceinline__ bool ing_sep(IngCursor& c) {
-  const uint32_t ch = c.peek();
-  if (ch == ',' || ch == '\t') { ++c.p; return true; }
-  return false;
-}
-
-// Parse one data row starting at c.p.  Returns false when malformed.
-__device__ __forceinline__ bool ing_row(IngCursor& c, const IngestArgs& a, int32_t& oid, int32_t& pidx, int32_t& qty) {
-  const int start = c.p;
-  if (c.peek() == '(') ++c.p;
-  ing_skip_sp(c);
-  if (!ing_int(c, oid)) return false;
-  ing_skip_sp(c);
-  if (!ing_sep(c)) return false;
-  ing_skip_sp(c);
-  // product code: up to 30 bytes, packed into four 64-bit words (NUL padded) and hashed (FNV-1a)
-  unsigned long long k[4] = {0, 0, 0, 0};
-  int len = 0;
-  uint32_t ch = c.peek();
-  auto take = [&](uint32_t b) {
-    if (len < 32) k[len >> 3] |= (unsigned long long)b << (8 * (len & 7));
-    ++len;
+// Host: fill the transition table T[kNumStates][kNumClasses] and the byte-class table CT[256].
+inline void ing_build_tables(unsigned long long* T, unsigned char* CT) {
+  for (int c = 0; c < 256; ++c) CT[c] = (unsigned char)ing_class_of(c);
+  int next[kNumStates][kNumClasses];
+  for (int s = 0; s < kNumStates; ++s)
+    for (int c = 0; c < kNumClasses; ++c) next[s][c] = s == sDone ? sDone : sErr;
+  auto int_start = [&](int s, int q1, int q2, int neg, int dig) {        // before an int: [q] ['-'] digits
+    next[s][kcSp] = s == sStart ? sASp : s;
+    next[s][kcQ1] = q1; next[s][kcQ2] = q2; next[s][kcMinus] = neg; next[s][kcDig] = dig;
   };
-  if (ch == '\'' || ch == '"') {
-    const uint32_t qt = ch;
-    ++c.p;
-    for (ch = c.peek(); ch != qt && ch != '\n'; ch = c.peek()) { take(ch); ++c.p; }
-    if (ch != qt) return false;
-    ++c.p;
-    if (c.peek() == qt) return false;               // doubled quote: an escape this grammar does not take
-  } else {
-    for (; ch != ',' && ch != '\t' && ch != ' ' && ch != '\r' && ch != ')' && ch != '\n'; ch = c.peek()) { take(ch); ++c.p; }
+  int_start(sStart, sAQ1, sAQ2, sANeg, sADig);
+  next[sStart][kcLpar] = sASp;
+  int_start(sASp, sAQ1, sAQ2, sANeg, sADig);
+  int_start(sDSp, sDQ1, sDQ2, sDNeg, sDDig);
+  next[sAQ1][kcMinus] = sANegQ1; next[sAQ1][kcDig] = sADigQ1;
+  next[sAQ2][kcMinus] = sANegQ2; next[sAQ2][kcDig] = sADigQ2;
+  next[sANeg][kcDig] = sADig; next[sANegQ1][kcDig] = sADigQ1; next[sANegQ2][kcDig] = sADigQ2;
+  next[sDQ1][kcMinus] = sDNegQ1; next[sDQ1][kcDig] = sDDigQ1;
+  next[sDQ2][kcMinus] = sDNegQ2; next[sDQ2][kcDig] = sDDigQ2;
+  next[sDNeg][kcDig] = sDDig; next[sDNegQ1][kcDig] = sDDigQ1; next[sDNegQ2][kcDig] = sDDigQ2;
+  // first int: digits, then (closing quote) spaces and the separator
+  next[sADig][kcDig] = sADig; next[sADig][kcSp] = sAEnd; next[sADig][kcComma] = sBSp; next[sADig][kcTab] = sBSp;
+  next[sADigQ1][kcDig] = sADigQ1; next[sADigQ1][kcQ1] = sAEnd;
+  next[sADigQ2][kcDig] = sADigQ2; next[sADigQ2][kcQ2] = sAEnd;
+  next[sAEnd][kcSp] = sAEnd; next[sAEnd][kcComma] = sBSp; next[sAEnd][kcTab] = sBSp;
+  // code: quoted, or bare up to one of , \t space \r \n )
+  for (int c = 0; c < kNumClasses; ++c) {
+    const bool stop = c == kcComma || c == kcTab || c == kcSp || c == kcCr || c == kcNl || c == kcRpar;
+    if (!stop) { next[sBSp][c] = sCBare; next[sCBare][c] = sCBare; }
+    if (c != kcNl) { next[sCQ1][c] = sCQ1; next[sCQ2][c] = sCQ2; }
   }
-  if (len > 30) return false;
-  ing_skip_sp(c);
-  if (!ing_sep(c)) return false;
-  ing_skip_sp(c);
-  if (!ing_int(c, qty)) return false;
-  ing_skip_sp(c);
-  if (c.peek() == ')') ++c.p;
-  ch = c.peek();
-  if (ch == ',' || ch == ';') ++c.p;
-  if (c.peek() == '\r') ++c.p;
-  if (c.peek() != '\n') return false;
-  if (c.p - start > kIngMaxRow) return false;
-  // dictionary lookup: hash of the four packed words, then the 32 code bytes must be identical
-  pidx = -1;
-  const unsigned long long h = ing_code_hash(k);
-  uint32_t slot = (uint32_t)h & a.dict_mask;
-  for (;;) {
-    const int32_t cand = a.dict_idx[slot];
-    if (cand < 0) break;
-    if (a.dict_hash[slot] == h) {
-      const unsigned long long* cc = a.codes + (size_t)cand * 4;
-      if (cc[0] == k[0] && cc[1] == k[1] && cc[2] == k[2] && cc[3] == k[3]) { pidx = cand; break; }
+  next[sBSp][kcSp] = sBSp; next[sBSp][kcQ1] = sCQ1; next[sBSp][kcQ2] = sCQ2;
+  next[sBSp][kcComma] = sDSp; next[sBSp][kcTab] = sDSp;                  // empty bare code
+  next[sCQ1][kcQ1] = sCQEnd1; next[sCQ2][kcQ2] = sCQEnd2;
+  next[sCQEnd1][kcSp] = sCEnd; next[sCQEnd1][kcComma] = sDSp; next[sCQEnd1][kcTab] = sDSp;   // a doubled quote: error
+  next[sCQEnd2][kcSp] = sCEnd; next[sCQEnd2][kcComma] = sDSp; next[sCQEnd2][kcTab] = sDSp;
+  next[sCBare][kcSp] = sCEnd; next[sCBare][kcComma] = sDSp; next[sCBare][kcTab] = sDSp;
+  next[sCEnd][kcSp] = sCEnd; next[sCEnd][kcComma] = sDSp; next[sCEnd][kcTab] = sDSp;
+  // second int and the row's tail: spaces, ')', ',' or ';', '\r', '\n'
+  auto tail = [&](int s, bool sp, bool par, bool term, bool cr) {
+    if (sp) next[s][kcSp] = sESp;
+    if (par) next[s][kcRpar] = sEPar;
+    if (term) { next[s][kcComma] = sETerm; next[s][kcSemi] = sETerm; }
+    if (cr) next[s][kcCr] = sECr;
+    next[s][kcNl] = sDone;
+  };
+  next[sDDig][kcDig] = sDDig; tail(sDDig, true, true, true, true);
+  next[sDDigQ1][kcDig] = sDDigQ1; next[sDDigQ1][kcQ1] = sESp;
+  next[sDDigQ2][kcDig] = sDDigQ2; next[sDDigQ2][kcQ2] = sESp;
+  tail(sESp, true, true, true, true);
+  tail(sEPar, false, false, true, true);
+  tail(sETerm, false, false, false, true);
+  tail(sECr, false, false, false, false);
+
+  auto in_a = [](int s) { return s >= sASp && s <= sADigQ2; };          // inside the first int (prefix or digits)
+  auto pre_code = [&](int s) { return s == sStart || in_a(s) || s == sAEnd || s == sBSp; };
+  for (int s = 0; s < kNumStates; ++s) {
+    for (int c = 0; c < kNumClasses; ++c) {
+      const int n = next[s][c];
+      unsigned long long a = 0, b = 0;
+      if (s != sDone && s != sErr) {
+        if (n != sDone) a += 1ull << kALen;                              // every byte of the row but its '\n'
+        if (c == kcDig && (n == sADig || n == sADigQ1 || n == sADigQ2)) a += 1ull << kANd1;
+        if (c == kcDig && (n == sDDig || n == sDDigQ1 || n == sDDigQ2)) a += 1ull << kANd2;
+        if (n == sANeg || n == sANegQ1 || n == sANegQ2) a += 1ull << kANeg1;
+        if (n == sDNeg || n == sDNegQ1 || n == sDNegQ2) a += 1ull << kANeg2;
+        if (n == sCBare || ((s == sCQ1 || s == sCQ2) && n == s)) a += 1ull << kACl;
+        if (in_a(n)) b += 1ull << kBE1;
+        if (pre_code(s) && (in_a(n) || n == sAEnd || n == sBSp || n == sCQ1 || n == sCQ2)) b += 1ull << kBCs;
+        if (n < sESp) b += 1ull << kBE2;
+      }
+      b |= (unsigned long long)(n * kNumClasses) << kBState;
+      T[s * kNumClasses + c] = (a << 32) | b;
     }
-    slot = (slot + 1u) & a.dict_mask;
   }
-  return true;
+}
+
+// hi:lo shifted right by sh bytes (sh = 0..3), low word.
+__device__ __forceinline__ uint32_t ing_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
+  return __builtin_amdgcn_alignbyte(hi, lo, sh);
+}
+
+// Four ASCII digits, most significant in the lowest byte (bytes already reduced to 0..9) -> 0..9999.
+__device__ __forceinline__ uint32_t ing_four_digits(uint32_t y) {
+  uint32_t t = (y << 3) + (y >> 8);
+  t += y << 1;                                    // byte 0: 10*d0 + d1, byte 2: 10*d2 + d3 (each < 100)
+  return (t & 0xffu) * 100u + ((t >> 16) & 0xffu);
+}
+
+// Value of the nd (1..10) decimal digits that end just before byte `pe` of the LDS text (pe >= 12).
+__device__ __forceinline__ unsigned long long ing_digits_value(const unsigned char* s_text, int pe, int nd) {
+  const int p0 = pe - 12;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(s_text) + (p0 >> 2);
+  const uint32_t sh = (uint32_t)p0 & 3u;
+  const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3];
+  const uint32_t x[3] = {ing_alignbyte(d1, d0, sh), ing_alignbyte(d2, d1, sh), ing_alignbyte(d3, d2, sh)};
+  const int drop = 12 - nd;                       // bytes in front of the number (little endian: low bytes first)
+  uint32_t v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int di = min(max(drop - 4 * i, 0), 4);
+    const uint32_t mask = di >= 4 ? 0u : (0xffffffffu << (8 * di));
+    v[i] = ing_four_digits(x[i] & mask & 0x0f0f0f0fu);
+  }
+  return (unsigned long long)v[0] * 100000000ull + (unsigned long long)(v[1] * 10000u + v[2]);
+}
+
+// Parse the data row that starts at byte `p` of the LDS text.  Returns false when malformed.
+__device__ __forceinline__ bool ing_row(const unsigned char* s_text, const unsigned char* s_ct, const uint2* s_T, int p,
+                                        const IngestArgs& a, int32_t& oid, int32_t& pidx, int32_t& qty) {
+  uint32_t st16 = sStart * kNumClasses, A = 0, B = 0;
+  const unsigned char* row = s_text + p;
+  for (int j0 = 0; j0 < ((a.ablate & 4) ? 8 : kIngSteps); j0 += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t cls = s_ct[row[j0 + j]];
+      const uint2 e = s_T[st16 + cls];
+      B += e.x;
+      A += e.y;
+      st16 = e.x >> kBState;
+    }
+    if (__ballot(st16 < (uint32_t)(sDone * kNumClasses)) == 0ull) break;      // every active lane is done
+  }
+  const int nd1 = (A >> kANd1) & 127, nd2 = (A >> kANd2) & 127, cl = (A >> kACl) & 127, len = (A >> kALen) & 127;
+  const bool neg1 = (A >> kANeg1) & 1u, neg2 = (A >> kANeg2) & 1u;
+  const int e1 = (B >> kBE1) & 127, cs = (B >> kBCs) & 127, e2 = (B >> kBE2) & 127;
+  bool ok = st16 == (uint32_t)(sDone * kNumClasses) && len <= kIngMaxRow && nd1 <= 10 && nd2 <= 10 && cl <= 30;
+  const unsigned long long v1 = ing_digits_value(s_text, p + e1, min(nd1, 10));
+  const unsigned long long v2 = ing_digits_value(s_text, p + e2, min(nd2, 10));
+  ok = ok && v1 <= (neg1 ? 2147483648ull : 2147483647ull) && v2 <= (neg2 ? 2147483648ull : 2147483647ull);
+  oid = (int32_t)(neg1 ? 0u - (uint32_t)v1 : (uint32_t)v1);
+  qty = (int32_t)(neg2 ? 0u - (uint32_t)v2 : (uint32_t)v2);
+  // the code: cl bytes from p + cs, as four NUL-padded little-endian 64-bit words
+  const int pc = p + cs;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(s_text) + (pc >> 2);
+  const uint32_t sh = (uint32_t)pc & 3u;
+  uint32_t cw[8];
+  uint32_t lo = w[0];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t hi = w[i + 1];
+    const int keep = min(max(cl - 4 * i, 0), 4);
+    const uint32_t mask = keep >= 4 ? 0xffffffffu : ((1u << (8 * keep)) - 1u);
+    cw[i] = ing_alignbyte(hi, lo, sh) & mask;
+    lo = hi;
+  }
+  pidx = -1;
+  if (ok && !(a.ablate & 2)) {
+    // dictionary lookup: bucket displacement (a small, cache-resident table), then the one slot this code
+    // can live in; the slot holds the code itself, so equality is decided without another round trip
+    const IngHash h = ing_code_hash(cw, a.dict_seed);
+    const uint32_t slot = ing_slot_of(h, a.dict_disp[h.a >> a.dict_bucket_shift], a.dict_mask);
+    const uint4* sp = reinterpret_cast<const uint4*>(a.dict + slot);
+    const uint4 s0 = sp[0], s1 = sp[1], s2 = sp[2];
+    const uint32_t diff = (s0.x ^ cw[0]) | (s0.y ^ cw[1]) | (s0.z ^ cw[2]) | (s0.w ^ cw[3]) | (s1.x ^ cw[4]) |
+                          (s1.y ^ cw[5]) | (s1.z ^ cw[6]) | (s1.w ^ cw[7]);
+    if (diff == 0u) pidx = (int32_t)s2.x;               // an empty slot holds the all-zero code and index -1
+  }
+  return ok;
 }
 
 __global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
-  __shared__ __align__(16) unsigned char s_text[kIngChunk + kIngLook + 16];
+  // [16 bytes of slack][chunk][look-ahead][slack]: number and code windows may reach a few bytes outside a row
+  __shared__ __align__(16) unsigned char s_text[kIngFront + kIngChunk + kIngLook + 64];
   // start offsets of the chunk's data rows, in text order (a data row takes at least two bytes)
   __shared__ unsigned short s_row[kIngChunk / 2];
+  __shared__ __align__(8) uint2 s_T[kIngTableWords];
+  __shared__ unsigned char s_ct[256];
   __shared__ int s_w[kIngThreads / 64];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < kIngTableWords; i += kIngThreads) {
+    const unsigned long long e = a.tables[i];
+    s_T[i] = make_uint2((uint32_t)e, (uint32_t)(e >> 32));
+  }
+  s_ct[tid] = reinterpret_cast<const unsigned char*>(a.tables + kIngTableWords)[tid];
+  if (tid < kIngFront) s_text[tid] = 0;
+  unsigned char* s_chunk = s_text + kIngFront;
   unsigned long long bad = 0;
   for (int64_t c = blockIdx.x; c < a.n_chunks; c += gridDim.x) {
     const int64_t cbase = c * kIngChunk;
@@ -263,12 +419,12 @@ __global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
     const int want = (int)(avail < kIngChunk + kIngLook ? avail : kIngChunk + kIngLook);
     for (int o = tid * 16; o < want; o += kIngThreads * 16) {
       if (o + 16 <= want) {
-        *reinterpret_cast<uint4*>(s_text + o) = *reinterpret_cast<const uint4*>(a.text + cbase + o);
+        *reinterpret_cast<uint4*>(s_chunk + o) = *reinterpret_cast<const uint4*>(a.text + cbase + o);
       } else {
-        for (int b = o; b < want; ++b) s_text[b] = a.text[cbase + b];
+        for (int b = o; b < want; ++b) s_chunk[b] = a.text[cbase + b];
       }
     }
-    if (tid == 0) s_text[want] = (unsigned char)'\n';     // sentinel: the parser stops at a newline
+    if (tid == 0) s_chunk[want] = (unsigned char)'\n';     // sentinel: every row ends in a newline
     __syncthreads();
     const int64_t base = cbase + (int64_t)tid * kIngPerThread;
     // line starts in this thread's 64 bytes, then the data rows among them (first one or two bytes)
@@ -279,22 +435,22 @@ __global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (o + 16 * j + 16 <= want) v = *reinterpret_cast<const uint4*>(s_text + o + 16 * j);
+        if (o + 16 * j + 16 <= want) v = *reinterpret_cast<const uint4*>(s_chunk + o + 16 * j);
         else {
           uint32_t t4[4] = {0, 0, 0, 0};
-          for (int b = 0; b < 16; ++b) if (o + 16 * j + b < want) t4[b >> 2] |= (uint32_t)s_text[o + 16 * j + b] << (8 * (b & 3));
+          for (int b = 0; b < 16; ++b) if (o + 16 * j + b < want) t4[b >> 2] |= (uint32_t)s_chunk[o + 16 * j + b] << (8 * (b & 3));
           v = make_uint4(t4[0], t4[1], t4[2], t4[3]);
         }
         w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
       }
-      const uint32_t prev = base == 0 ? (uint32_t)'\n' : (tid == 0 ? (uint32_t)a.text[base - 1] : (uint32_t)s_text[o - 1]);
+      const uint32_t prev = base == 0 ? (uint32_t)'\n' : (tid == 0 ? (uint32_t)a.text[base - 1] : (uint32_t)s_chunk[o - 1]);
       unsigned long long smask = ing_line_start_mask(w, prev);
       const int64_t left = a.n_bytes - base;                 // bytes of text from this thread's first byte on
       if (left < 64) smask &= (1ull << left) - 1ull;
       for (unsigned long long m = smask; m; m &= m - 1ull) {
         const int k = __ffsll((long long)m) - 1;
-        const uint32_t c0 = s_text[o + k];
-        const uint32_t c1 = k + 1 < left ? (uint32_t)s_text[o + k + 1] : 0u;
+        const uint32_t c0 = s_chunk[o + k];
+        const uint32_t c1 = k + 1 < left ? (uint32_t)s_chunk[o + k + 1] : 0u;
         if (ing_data_row(c0, c1)) dmask |= 1ull << k;
       }
     }
@@ -315,11 +471,8 @@ __global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
     __syncthreads();
     const long long rbase = a.chunk_rows[c];
     for (r = tid; r < n_r; r += kIngThreads) {
-      IngCursor cur;
-      cur.s = s_text;
-      cur.p = (int)s_row[r];
       int32_t oid = 0, pidx = -1, qty = 0;
-      const bool ok = ing_row(cur, a, oid, pidx, qty);
+      const bool ok = (a.ablate & 1) ? true : ing_row(s_text, s_ct, s_T, kIngFront + (int)s_row[r], a, oid, pidx, qty);
       if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
       const long long row = rbase + r;
       if (row < a.capacity) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }

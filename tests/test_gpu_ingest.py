@@ -101,6 +101,45 @@ def test_fuzzed_text_row_for_row(motor, oracle):
     np.testing.assert_array_equal(qty, eqty)
 
 
+def test_fuzzed_bytes_full_alphabet(motor, oracle):
+    """Every byte value (a vertical tab or 0x01 right after a newline must not look like a line start),
+    leading zeros, 9 to 12 digit numbers around the int32 limits, rows of 119 to 122 bytes."""
+    import ctypes as C
+    rng = np.random.default_rng(47)
+    codes = ["1", "2", "ab", "SKU-1", "x" * 30, "\x0b5", "caf\xe9"]
+    lines = []
+    for i in range(80_000):
+        r = rng.random()
+        if r < 0.35:
+            a = rng.choice(["0000000005", "2147483647", "2147483648", "-2147483648", "-2147483649", "4294967301",
+                            "99999999999", "000000000000", "0", "-0", "12345678901", str(int(rng.integers(0, 10**10)))])
+            q = rng.choice(["1", "007", "-3", "2147483647", "9999999999", "00000000001", ""])
+            c = codes[int(rng.integers(0, len(codes)))]
+            ln = rng.choice([f"({a}, '{c}', {q}),", f"{a},{c},{q}", f"\"{a}\",\"{c}\",\"{q}\"", f"({a},'{c}',{q});\r"]).encode("latin-1")
+        elif r < 0.8:
+            ln = bytes(int(b) for b in rng.integers(0, 256, int(rng.integers(0, 40))))
+            if rng.random() < 0.5:
+                ln = rng.choice([b"5,", b"(7, '", b"-1\t", b"'3',"]) + ln
+        else:
+            pad = int(rng.integers(100, 112))
+            ln = b"(1, '1',  " + b" " * pad + b"1),"                  # 113 + pad - 100 ... around the 120-byte limit
+            ln = ln[:int(rng.integers(117, 124))] if rng.random() < 0.5 else ln
+        lines.append(ln.replace(b"\n", b"\x0b"))
+    text = b"\n".join(lines)
+    ingesta.cargar_codigos(motor, codes)
+    eoid, epidx, eqty, n, bad = oracle.ingest(text, codes)
+    roid, rpidx, rqty, rbad = ic.reference_parse(text, codes)
+    assert (roid.size, rbad) == (n, bad) and np.array_equal(roid, eoid) and np.array_equal(rpidx, epidx) and np.array_equal(rqty, eqty)
+    oid, pidx, qty = (np.empty(n, np.int32) for _ in range(3))
+    gn, gbad = C.c_int64(0), C.c_int64(0)
+    rc = motor._lib.acmpc_ingest_detalle(motor._ctx, text, len(text), oid.ctypes.data, pidx.ctypes.data, qty.ctypes.data,
+                                         n, C.byref(gn), C.byref(gbad))
+    assert rc == _lib.E_DATA and (gn.value, gbad.value) == (n, bad) and bad > 1000 and n - bad > 1000
+    np.testing.assert_array_equal(oid, eoid)
+    np.testing.assert_array_equal(pidx, epidx)
+    np.testing.assert_array_equal(qty, eqty)
+
+
 def test_capacity_too_small_is_reported(motor):
     ingesta.cargar_codigos(motor, ["1"])
     with pytest.raises(ErrorLote) as e:

@@ -24,6 +24,7 @@ for style in ("dump", "csv"):
         ingesta.leer_detalle_device(m, text, oid, pidx, qty, cnt)
     m.estado()
     assert int(cnt.item()) == n_rows, (int(cnt.item()), n_rows)
+    ablated = bool(int(os.environ.get("ACMPC_ING_ABLATE", "0")))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
@@ -35,6 +36,8 @@ for style in ("dump", "csv"):
     alg = nb + 12 * n_rows
     print(f"{style:5s} {n_rows} rows, {nb/1e9:.2f} GB text ({nb/n_rows:.1f} B/row): {ms:.3f} ms  "
           f"{n_rows/ms/1e6:.1f} G rows/s  {nb/ms/1e6:.0f} GB/s of text  algorithmic {alg/ms/1e6:.0f} GB/s = {alg/ms/1e6/8000*100:.1f}% of 8 TB/s")
+    if ablated:
+        continue
     t0 = time.perf_counter(); orc.ingest(block, codes); dt = time.perf_counter() - t0
     print(f"      C oracle, 1 thread: {1e6/dt/1e6:.2f} M rows/s, {len(block)/dt/1e9:.3f} GB/s")
     # spot check
