@@ -69,7 +69,7 @@ struct acmpc_ctx {
   DevBuf<unsigned short> d_dict_disp;
   uint32_t dict_seed = 0, dict_bucket_shift = 0;
   DevBuf<unsigned long long> d_codes;
-  DevBuf<long long> d_chunk_rows;
+  DevBuf<unsigned long long> d_chunk_rows;   // per-chunk row-count entries of the ingest, then its ticket
   DevBuf<unsigned long long> d_ing_tables;   // row automaton: transition entries, then the byte classes
   long long* d_ing_scalars = nullptr;      // [0] rows found, [1] malformed rows
   DevBuf<unsigned char> s_text;
@@ -652,12 +652,14 @@ ACMPC_API int acmpc_status(acmpc_ctx* ctx, void* hip_stream, uint32_t* flags) {
   HIPCHK(ctx, hipStreamSynchronize(st));
   if (flags) *flags = f;
   if (f)
-    return fail(ctx, ACMPC_E_DATA, "data contract broken:%s%s%s%s%s",
+    return fail(ctx, ACMPC_E_DATA, "data contract broken:%s%s%s%s%s%s%s",
                 (f & ACMPC_ST_ORDER_RANGE) ? " order_id outside [base, base+M);" : "",
                 (f & ACMPC_ST_ORDER_UNSORTED) ? " order_id not non-decreasing;" : "",
                 (f & ACMPC_ST_CUSTOMER_RANGE) ? " order_customer outside [0, C);" : "",
                 (f & ACMPC_ST_INGEST_MALFORMED) ? " malformed detalle row in the text;" : "",
-                (f & ACMPC_ST_INGEST_CAPACITY) ? " more detalle rows than capacity_rows;" : "");
+                (f & ACMPC_ST_INGEST_CAPACITY) ? " more detalle rows than capacity_rows;" : "",
+                (f & ACMPC_ST_EMIT_CAPACITY) ? " emitted text needs more than capacity_bytes;" : "",
+                (f & ACMPC_ST_INTERNAL) ? " internal: a chunk waited too long for its predecessors;" : "");
   return ACMPC_OK;
 }
 
@@ -968,7 +970,8 @@ ACMPC_API int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, in
   a.n_chunks = (n_bytes + kIngChunk - 1) / kIngChunk;
   int rc;
   if ((rc = ensure(ctx, ctx->d_chunk_rows, (size_t)a.n_chunks + 1))) return rc;
-  a.chunk_rows = ctx->d_chunk_rows.p;
+  a.chunk_state = ctx->d_chunk_rows.p;
+  a.ticket = reinterpret_cast<unsigned int*>(ctx->d_chunk_rows.p + a.n_chunks);
   a.dict = ctx->d_dict.p; a.dict_disp = ctx->d_dict_disp.p; a.dict_mask = ctx->dict_mask;
   a.dict_seed = ctx->dict_seed; a.dict_bucket_shift = ctx->dict_bucket_shift;
   a.codes = ctx->d_codes.p;
@@ -983,12 +986,9 @@ ACMPC_API int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, in
     HIPCHK(ctx, hipMemsetAsync(d_n_rows, 0, sizeof(int64_t), st));
     return ACMPC_OK;
   }
-  const int blocks = (int)std::min<int64_t>(a.n_chunks, (int64_t)ctx->n_cu * 8);
-  hipLaunchKernelGGL(k_ingest_count, dim3(blocks), dim3(kIngThreads), 0, st, a);
-  HIPCHK(ctx, hipGetLastError());
-  ScanArgs sc{a.chunk_rows, a.n_chunks, a.n_rows, capacity_rows, a.status, kStIngestCapacity};
-  hipLaunchKernelGGL(k_chunk_scan, dim3(1), dim3(1024), 0, st, sc);
-  HIPCHK(ctx, hipGetLastError());
+  // entries and ticket start at zero; chunks are handed out in order, so any grid size is safe
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_chunk_rows.p, 0, ((size_t)a.n_chunks + 1) * 8, st));
+  const int blocks = (int)std::min<int64_t>(a.n_chunks, (int64_t)ctx->n_cu * 4);
   hipLaunchKernelGGL(k_ingest_parse, dim3(blocks), dim3(kIngThreads), 0, st, a);
   HIPCHK(ctx, hipGetLastError());
   return ACMPC_OK;

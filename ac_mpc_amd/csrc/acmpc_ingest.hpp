@@ -6,10 +6,8 @@
 // store.sql:88-89,125-128 (header line, one "(v, 'v', v)," row per line) and plain comma / tab
 // separated rows.  The grammar is spelled out in include/acmpc.h.
 //
-// Two passes over the text (byte work, HBM-bandwidth bound; no MFMA):
-//   k_ingest_count   every 16 KiB chunk counts the data rows that START in it
-//   k_chunk_scan     exclusive prefix of the chunk counts (one workgroup)
-//   k_ingest_parse   every chunk is staged in LDS (plus 128 bytes of lookahead); each thread finds
+// One pass over the text (byte work; no MFMA):
+//   k_ingest_parse   16 KiB chunks are handed out in order; every chunk is staged in LDS (plus 128 bytes of lookahead); each thread finds
 //                    the row starts in its 64 bytes and ranks them with a block scan; the rows are
 //                    then handed out one per thread, run through a table-driven automaton, converted,
 //                    looked up in a hash dictionary of the product codes and written as columns
@@ -32,7 +30,8 @@ struct IngestArgs {
   const unsigned char* text;
   int64_t n_bytes;
   int64_t n_chunks;
-  long long* chunk_rows;              // [n_chunks + 1]: counts, then exclusive offsets; last = total
+  unsigned long long* chunk_state;    // [n_chunks] zero on entry: see ing_row_base
+  unsigned int* ticket;               // zero on entry: next chunk to hand out
   const IngSlot* dict;            // perfect-hash dictionary of the product codes: one slot per probe
   const unsigned short* dict_disp;       // displacement of every bucket
   uint32_t dict_mask, dict_seed, dict_bucket_shift;
@@ -61,34 +60,6 @@ __device__ __forceinline__ uint32_t ing_newlines(uint32_t w) {
   return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;    // exact per byte: no borrow between bytes
 }
 
-// Calls f(offset) for every data-row start among the 64 text bytes held in w[16] (offset 0..63 is
-// relative to the thread's first byte).  prev is the byte before the thread's range ('\n' at the
-// start of the text), next2 holds the two bytes after it (0 past the end of the text).
-template <typename F>
-__device__ __forceinline__ void ing_row_starts(const uint32_t (&w)[16], uint32_t prev, uint32_t next2, int64_t base,
-                                               int64_t n_bytes, F f) {
-  // a row starts at byte k iff byte k-1 is '\n'; shift the newline mask by one byte
-  uint32_t carry = prev == '\n' ? 0x80u : 0u;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const uint32_t nl = ing_newlines(w[j]);
-    uint32_t starts = (nl << 8) | carry;             // bit 7 of byte b set: a row starts at byte 4j+b
-    carry = nl >> 24;
-    while (starts) {
-      const int b = (__ffs((int)starts) - 1) >> 3;
-      starts &= starts - 1u;
-      const int k = 4 * j + b;
-      if (base + k >= n_bytes) continue;
-      // the row's first two bytes: inside w, or next2 at the very end of the range
-      const uint32_t lo = j < 15 ? w[j + 1 < 16 ? j + 1 : 15] : next2;
-      const unsigned long long pair = ((unsigned long long)lo << 32) | w[j];
-      const uint32_t c0 = (uint32_t)(pair >> (8 * b)) & 0xffu;
-      const uint32_t c1 = (uint32_t)(pair >> (8 * b + 8)) & 0xffu;
-      if (ing_data_row(c0, base + k + 1 < n_bytes ? c1 : 0u)) f(k);
-    }
-  }
-}
-
 // Bit k set: a line starts at byte k of the thread's 64 bytes (byte k-1 is '\n', or the text starts
 // there).  Lines are not classified here.
 __device__ __forceinline__ unsigned long long ing_line_start_mask(const uint32_t (&w)[16], uint32_t prev) {
@@ -105,51 +76,71 @@ __device__ __forceinline__ unsigned long long ing_line_start_mask(const uint32_t
   return mask;
 }
 
-// Load the thread's 64 bytes (zero past the end of the text) and its neighbours.
-__device__ __forceinline__ void ing_load64(const unsigned char* text, int64_t n_bytes, int64_t base, uint32_t (&w)[16],
-                                           uint32_t& prev, uint32_t& next2) {
-  if (base + kIngPerThread <= n_bytes) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint4 v = *reinterpret_cast<const uint4*>(text + base + 16 * j);
-      w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      uint32_t v = 0;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int64_t p = base + 4 * j + b;
-        if (p < n_bytes) v |= (uint32_t)text[p] << (8 * b);
-      }
-      w[j] = v;
-    }
-  }
-  prev = base == 0 ? (uint32_t)'\n' : (base - 1 < n_bytes ? (uint32_t)text[base - 1] : 0u);
-  uint32_t n0 = base + kIngPerThread < n_bytes ? text[base + kIngPerThread] : 0u;
-  uint32_t n1 = base + kIngPerThread + 1 < n_bytes ? text[base + kIngPerThread + 1] : 0u;
-  next2 = n0 | (n1 << 8);
+// ---------------------------------------------------------------------------------------------
+// Row base of a chunk without a counting pass: chunks are taken in order from a ticket counter, every
+// chunk publishes its row count as soon as it knows it, and looks back over its predecessors' entries
+// (512 at a time) until it meets one that already holds an inclusive prefix.  An entry is one 64-bit
+// word: the top two bits say empty / own count / inclusive prefix, the rest is the value, so one
+// relaxed atomic store publishes both.  A chunk only ever waits for chunks with smaller tickets, which
+// were handed to workgroups that are already running.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned long long kIngOwn = 1ull << 62, kIngInclusive = 2ull << 62, kIngValue = (1ull << 62) - 1ull;
+constexpr uint32_t kStInternal = 64u;
+
+// Publish the chunk's own row count (one thread).  Done as early as possible: successors can then add
+// it up long before this chunk knows its own base.
+__device__ __forceinline__ void ing_publish_own(unsigned long long* state, long long c, long long n_r) {
+  __hip_atomic_store(&state[c], (c == 0 ? kIngInclusive : kIngOwn) | (unsigned long long)n_r, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void __launch_bounds__(kIngThreads) k_ingest_count(IngestArgs a) {
-  __shared__ int s_w[kIngThreads / 64];
-  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int64_t c = blockIdx.x; c < a.n_chunks; c += gridDim.x) {
-    const int64_t base = c * kIngChunk + (int64_t)tid * kIngPerThread;
-    int cnt = 0;
-    if (base < a.n_bytes) {
-      uint32_t w[16], prev, next2;
-      ing_load64(a.text, a.n_bytes, base, w, prev, next2);
-      ing_row_starts(w, prev, next2, base, a.n_bytes, [&](int) { ++cnt; });
+// Called by one whole wave, after ing_publish_own.  Returns the number of data rows in chunks [0, c)
+// and publishes the chunk's inclusive prefix.
+__device__ __forceinline__ long long ing_row_base(unsigned long long* state, long long c, long long n_r, int lane,
+                                                  uint32_t* status) {
+  if (c == 0) return 0;
+  long long excl = 0;
+  long long p = c - 1;                                   // nearest predecessor not yet added
+  constexpr int kPer = 1;                                // entries per lane and round
+  for (uint32_t polls = 0;;) {
+    // lane l looks at the entries at distance 8l .. 8l+7 behind p (nearest first)
+    unsigned long long v[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const long long idx = p - ((long long)lane * kPer + j);
+      v[j] = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                      : kIngInclusive;                   // in front of chunk 0: nothing
+    }
+    int fj = kPer;                                       // this lane's nearest inclusive entry
+#pragma unroll
+    for (int j = kPer - 1; j >= 0; --j) fj = (v[j] >> 62) == 2ull ? j : fj;
+    const unsigned long long incl_mask = __ballot(fj < kPer);
+    const int first = incl_mask ? __ffsll((long long)incl_mask) - 1 : 64;     // lane holding the nearest one
+    // entries nearer than (and including) that one must all be published
+    const int upto = lane < first ? kPer - 1 : (lane == first ? fj : -1);
+    bool waiting = false;
+    long long val = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      if (j <= upto) {
+        waiting |= (v[j] >> 62) == 0ull;
+        val += (long long)(v[j] & kIngValue);
+      }
+    }
+    if (__ballot(waiting)) {                             // a predecessor has not published yet
+      if (++polls > (1u << 24)) { if (lane == 0) atomicOr(status, kStInternal); break; }   // never expected
+      __builtin_amdgcn_s_sleep(2);
+      continue;
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
-    if (lane == 0) s_w[wave] = cnt;
-    __syncthreads();
-    if (tid == 0) a.chunk_rows[c] = (long long)s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    __syncthreads();
+    for (int d = 32; d > 0; d >>= 1) val += __shfl_xor(val, d);
+    excl += val;
+    if (incl_mask) break;
+    p -= 64 * kPer;
   }
+  if (lane == 0)
+    __hip_atomic_store(&state[c], kIngInclusive | (unsigned long long)(excl + n_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
 }
 
 // Two hashes of a product code given as its 32 NUL-padded bytes in eight little-endian 32-bit words.
@@ -399,10 +390,13 @@ __global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
   // [16 bytes of slack][chunk][look-ahead][slack]: number and code windows may reach a few bytes outside a row
   __shared__ __align__(16) unsigned char s_text[kIngFront + kIngChunk + kIngLook + 64];
   // start offsets of the chunk's data rows, in text order (a data row takes at least two bytes)
-  __shared__ unsigned short s_row[kIngChunk / 2];
+  __shared__ __align__(16) unsigned short s_row[kIngChunk / 2];
+  static_assert(kIngChunk / 2 * 2 >= 1024 * 2 + 3 * 1024 * 4, "parsed columns are parked behind the row list");
   __shared__ __align__(8) uint2 s_T[kIngTableWords];
   __shared__ unsigned char s_ct[256];
   __shared__ int s_w[kIngThreads / 64];
+  __shared__ long long s_base;
+  __shared__ unsigned int s_ticket;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < kIngTableWords; i += kIngThreads) {
     const unsigned long long e = a.tables[i];
@@ -412,7 +406,11 @@ __global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
   if (tid < kIngFront) s_text[tid] = 0;
   unsigned char* s_chunk = s_text + kIngFront;
   unsigned long long bad = 0;
-  for (int64_t c = blockIdx.x; c < a.n_chunks; c += gridDim.x) {
+  for (;;) {
+    if (tid == 0) s_ticket = atomicAdd(a.ticket, 1u);      // chunks are handed out in text order
+    __syncthreads();
+    const int64_t c = (int64_t)s_ticket;
+    if (c >= a.n_chunks) break;                            // uniform
     const int64_t cbase = c * kIngChunk;
     // stage chunk + lookahead (16-byte pieces; the text buffer is padded by the host side)
     const int64_t avail = a.n_bytes - cbase;
@@ -464,18 +462,54 @@ __global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
     int woff = 0, n_r = 0;
 #pragma unroll
     for (int k = 0; k < kIngThreads / 64; ++k) { if (k < wave) woff += s_w[k]; n_r += s_w[k]; }
+    if (tid == 0 && !(a.ablate & 64)) ing_publish_own(a.chunk_state, c, n_r);
     // hand the rows out one per thread: every lane of a wave then parses a row of its own, and
     // consecutive lanes write consecutive output rows
     int r = woff + incl - cnt;
     for (unsigned long long m = dmask; m; m &= m - 1ull, ++r) s_row[r] = (unsigned short)(o + __ffsll((long long)m) - 1);
     __syncthreads();
-    const long long rbase = a.chunk_rows[c];
-    for (r = tid; r < n_r; r += kIngThreads) {
-      int32_t oid = 0, pidx = -1, qty = 0;
-      const bool ok = (a.ablate & 1) ? true : ing_row(s_text, s_ct, s_T, kIngFront + (int)s_row[r], a, oid, pidx, qty);
-      if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
-      const long long row = rbase + r;
-      if (row < a.capacity) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }
+    // The chunk's first output row comes from its predecessors' counts.  Looking back is cheapest when it
+    // is done late (the predecessors have had time to publish), so the rows are parsed first and parked
+    // in LDS; only a chunk with more rows than fit there looks back before parsing.
+    auto resolve_base = [&]() {
+      if (wave == 0) {
+        const long long excl = (a.ablate & 64) ? c * 600 : ing_row_base(a.chunk_state, c, n_r, lane, a.status);
+        if (lane == 0) {
+          s_base = excl;
+          if (c == a.n_chunks - 1) {                         // the last chunk knows the total
+            *a.n_rows = excl + n_r;
+            if (excl + n_r > a.capacity) atomicOr(a.status, kStIngestCapacity);
+          }
+        }
+      }
+      __syncthreads();
+    };
+    constexpr int kKeep = 1024;                              // parsed rows a chunk can park in LDS
+    if (n_r <= kKeep) {
+      // the row list needs n_r entries only; the rest of its space holds the parsed columns meanwhile
+      int32_t* s_res = reinterpret_cast<int32_t*>(s_row + kKeep);
+      for (r = tid; r < n_r; r += kIngThreads) {
+        int32_t oid = 0, pidx = -1, qty = 0;
+        const bool ok = (a.ablate & 1) ? true : ing_row(s_text, s_ct, s_T, kIngFront + (int)s_row[r], a, oid, pidx, qty);
+        if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
+        s_res[r] = oid; s_res[kKeep + r] = pidx; s_res[2 * kKeep + r] = qty;
+      }
+      resolve_base();
+      const long long rbase = s_base;
+      for (r = tid; r < n_r; r += kIngThreads) {               // every thread reads back its own rows
+        const long long row = rbase + r;
+        if (row < a.capacity) { a.order_id[row] = s_res[r]; a.product_idx[row] = s_res[kKeep + r]; a.qty[row] = s_res[2 * kKeep + r]; }
+      }
+    } else {
+      resolve_base();
+      const long long rbase = s_base;
+      for (r = tid; r < n_r; r += kIngThreads) {
+        int32_t oid = 0, pidx = -1, qty = 0;
+        const bool ok = ing_row(s_text, s_ct, s_T, kIngFront + (int)s_row[r], a, oid, pidx, qty);
+        if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
+        const long long row = rbase + r;
+        if (row < a.capacity) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }
+      }
     }
     __syncthreads();
   }

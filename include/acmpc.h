@@ -55,6 +55,7 @@ typedef struct acmpc_ctx acmpc_ctx;
 #define ACMPC_ST_CUSTOMER_RANGE  4u /* some order_customer outside [0, C)               */
 #define ACMPC_ST_INGEST_MALFORMED 8u /* acmpc_ingest_*: a data row did not match the grammar */
 #define ACMPC_ST_INGEST_CAPACITY 16u /* acmpc_ingest_*: more data rows than capacity_rows    */
+#define ACMPC_ST_INTERNAL        64u /* a device-side wait gave up (never expected): results of that call are invalid */
 
 /* Kernel slots of acmpc_last_kernel_ms(). */
 #define ACMPC_K_LINES      0   /* order-line pass: totals, stock deltas               */

@@ -140,6 +140,33 @@ def test_fuzzed_bytes_full_alphabet(motor, oracle):
     np.testing.assert_array_equal(qty, eqty)
 
 
+def test_dense_rows_empty_chunks_and_long_rows_keep_their_order(motor, oracle):
+    """Row bases come from a look-back over the chunks before: mix chunks with thousands of tiny rows (more
+    than a chunk can park), chunks without any data row and chunks of long rows, over many chunks."""
+    rng = np.random.default_rng(53)
+    codes = ["1", "2", "3"]
+    parts = []
+    k = 0
+    for block in range(120):
+        kind = block % 4
+        if kind == 0:
+            n = int(rng.integers(3000, 9000))
+            parts.append("".join(f"{(k + i) % 10},{1 + (k + i) % 3},{i % 7}\n" for i in range(n)))      # 6-byte rows
+        elif kind == 1:
+            parts.append("-- no data here\n" * int(rng.integers(1500, 4000)))                             # > 1 empty chunk
+            n = 0
+        elif kind == 2:
+            n = int(rng.integers(200, 600))
+            parts.append("".join(f"({k + i},  '{1 + i % 3}',      {i}    );\n" for i in range(n)))
+        else:
+            n = int(rng.integers(1, 40))
+            parts.append("".join(f"( {k + i} , '{'x' * 30}' , {i} ),\r\n" for i in range(n)))
+        k += n
+    text = "".join(parts).encode()
+    assert len(text) > 40 * 16384
+    _same(motor, oracle, text, codes)
+
+
 def test_capacity_too_small_is_reported(motor):
     ingesta.cargar_codigos(motor, ["1"])
     with pytest.raises(ErrorLote) as e:

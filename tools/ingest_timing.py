@@ -23,7 +23,7 @@ for style in ("dump", "csv"):
     for _ in range(2):
         ingesta.leer_detalle_device(m, text, oid, pidx, qty, cnt)
     m.estado()
-    assert int(cnt.item()) == n_rows, (int(cnt.item()), n_rows)
+    assert int(cnt.item()) == n_rows or os.environ.get("ACMPC_ING_ABLATE"), (int(cnt.item()), n_rows)
     ablated = bool(int(os.environ.get("ACMPC_ING_ABLATE", "0")))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
