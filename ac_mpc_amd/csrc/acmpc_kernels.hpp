@@ -744,6 +744,9 @@ __global__ void __launch_bounds__(kFixThreads) k_fixup(FixArgs a) {
     sums[k] = i < n ? a.rec_sum[i] : 0;
   }
   if (i0 > 0 && i0 < n) prev_id = a.rec_id[i0 - 1];
+  // everything this block reads from global memory is requested here, in one round trip
+  const int after_id = i0 + kFixStrip < n ? a.rec_id[i0 + kFixStrip] : 0;     // the id after this thread's strip
+  const int first_id = n > 0 ? a.rec_id[0] : 0, last_id = n > 0 ? a.rec_id[n - 1] : 0;
 
   long long tsum = 0;
   int tmax = -1;
@@ -787,7 +790,7 @@ __global__ void __launch_bounds__(kFixThreads) k_fixup(FixArgs a) {
   for (int k = 0; k < kFixStrip; ++k) {
     const int i = i0 + k;
     if (i < n) {
-      const int next_id = (i + 1 < n) ? ((k + 1 < kFixStrip) ? ids[(k + 1) % kFixStrip] : a.rec_id[i + 1]) : 0;
+      const int next_id = (i + 1 < n) ? ((k + 1 < kFixStrip) ? ids[(k + 1) % kFixStrip] : after_id) : 0;
       const bool tail = (i + 1 == n) || (next_id != ids[k]);
       if (tail) {
         const long long total = s_excl[i] + sums[k] - s_excl[s_head[i]];
@@ -818,8 +821,8 @@ __global__ void __launch_bounds__(kFixThreads) k_fixup(FixArgs a) {
                     a.n_orders);
   // orders before the first and after the last line
   if (n > 0) {
-    block_fill_zero(a.order_total, 0, (long long)a.rec_id[0] - a.base, a.n_orders);
-    block_fill_zero(a.order_total, (long long)a.rec_id[n - 1] + 1 - a.base, a.n_orders, a.n_orders);
+    block_fill_zero(a.order_total, 0, (long long)first_id - a.base, a.n_orders);
+    block_fill_zero(a.order_total, (long long)last_id + 1 - a.base, a.n_orders, a.n_orders);
   }
   if (st) atomicOr(a.status, st);
 }
