@@ -48,6 +48,9 @@ struct acmpc_ctx {
   DevBuf<unsigned long long> d_prod_carry;
   DevBuf<int32_t> d_rec_id;
   DevBuf<int64_t> d_rec_sum;
+  DevBuf<uint32_t> d_edge_idx;      // fused path: orders cut by wave boundaries, written after the customer pass
+  DevBuf<int64_t> d_edge_total;
+  int fuse = 1;                     // 0: always the four-launch sequence (ACMPC_FUSE=0)
   DevBuf<uint32_t> d_cust_slab;
   DevBuf<unsigned long long> d_cust_carry;
   uint32_t* d_status = nullptr;
@@ -337,6 +340,18 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     ctx->k1_lpl = keep;
   }
   int rc;
+  // The plain grouped path runs in three launches: the record block of k_fixup rides along with the
+  // customer pass, and one tail kernel does the merges.  Everything else keeps the four-launch sequence.
+  CustPlan cp;
+  if (n_orders > 0) plan_customers(ctx, n_orders, n_customers, &cp);
+  // (The record block needs some 40 us next to the customer pass: below a few million orders that pass is
+  // shorter and the four-launch sequence is quicker.  ACMPC_FUSE=2 forces the fused path for tests.)
+  const bool fused = ctx->fuse && ctx->line_order == ACMPC_ORDER_GROUPED && !life && n_lines > 0 &&
+                     (n_orders >= 4000000 || (ctx->fuse == 2 && n_orders > 0)) &&
+                     lp.lds_tables && cp.lds_tables && cp.threads == kFixThreads;
+  FixArgs f;
+  memset(&f, 0, sizeof(f));
+  const size_t fix_lds = (size_t)kFixThreads * kFixStrip * 12;
   if (n_lines == 0) {
     if (n_orders > 0) HIPCHK(ctx, hipMemsetAsync(d_tot, 0, (size_t)n_orders * 8, st));
     HIPCHK(ctx, hipMemsetAsync(d_pq, 0, (size_t)P * 8, st));
@@ -372,6 +387,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.price_in_lds = xpose_prices ? 0 : 1;
     a.only_if_unsorted = 0;
     a.totals_only = 0;
+    a.fill_edges = fused ? 1 : 0;
     a.order_state = d_state;
 
     ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
@@ -399,7 +415,6 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     if (rc) return rc;
     if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
 
-    FixArgs f;
     f.rec_id = ctx->d_rec_id.p; f.rec_sum = ctx->d_rec_sum.p; f.n_rec = 2 * lp.n_active_waves;
     f.base = base; f.n_orders = (int32_t)n_orders; f.order_total = d_tot; f.status = ctx->d_status;
     f.prod_slab = ctx->d_prod_slab.p; f.n_slabs = lp.blocks; f.p_pad = ctx->p_pad; f.n_products = P;
@@ -407,11 +422,12 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     f.fix_orders = any_order ? 0 : 1;
     f.prod_carry = ctx->d_prod_carry.p; f.product_qty = d_pq;
     f.ablate = env_int("ACMPC_FIX_ABLATE", 0);
-    const size_t fix_lds = (size_t)kFixThreads * kFixStrip * 12;
-    if ((rc = set_dyn_lds(ctx, k_fixup, fix_lds))) return rc;
-    const int fix_blocks = 1 + (lp.lds_tables ? (P + kMergeProducts - 1) / kMergeProducts : 0);
-    hipLaunchKernelGGL(k_fixup, dim3(fix_blocks), dim3(kFixThreads), fix_lds, st, f);
-    HIPCHK(ctx, hipGetLastError());
+    if (!fused) {
+      if ((rc = set_dyn_lds(ctx, k_fixup, fix_lds))) return rc;
+      const int fix_blocks = 1 + (lp.lds_tables ? (P + kMergeProducts - 1) / kMergeProducts : 0);
+      hipLaunchKernelGGL(k_fixup, dim3(fix_blocks), dim3(kFixThreads), fix_lds, st, f);
+      HIPCHK(ctx, hipGetLastError());
+    }
     if (!lp.lds_tables) {
       hipLaunchKernelGGL(k_move_clear, dim3((P + 255) / 256), dim3(256), 0, st, ctx->d_prod_carry.p, d_pq, P);
       HIPCHK(ctx, hipGetLastError());
@@ -453,8 +469,6 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     HIPCHK(ctx, hipMemsetAsync(d_ct, 0, (size_t)n_customers * 8, st));
     if (ctx->profiling) { HIPCHK(ctx, hipEventRecord(ctx->ev[3], st)); HIPCHK(ctx, hipEventRecord(ctx->ev[4], st)); }
   } else {
-    CustPlan cp;
-    plan_customers(ctx, n_orders, n_customers, &cp);
     if (ctx->d_cust_carry.cap < (size_t)n_customers) {
       if ((rc = ensure(ctx, ctx->d_cust_carry, (size_t)n_customers, true))) return rc;
     }
@@ -468,7 +482,21 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     c.ablate = env_int("ACMPC_K2_ABLATE", 0);
     c.order_state = d_state;
     ctx->carry_dirty = true;
-    if (cp.lds_tables && d_state) {
+    if (fused) {
+      if ((rc = ensure(ctx, ctx->d_edge_idx, (size_t)2 * kMaxWavesTotal))) return rc;
+      if ((rc = ensure(ctx, ctx->d_edge_total, (size_t)2 * kMaxWavesTotal))) return rc;
+      f.deferred = 1;
+      f.order_customer = d_order_customer; f.cust_carry = ctx->d_cust_carry.p; f.n_customers = n_customers;
+      f.edge_idx = ctx->d_edge_idx.p; f.edge_total = ctx->d_edge_total.p;
+      CustFusedArgs fa;
+      fa.c = c;
+      fa.f = f;
+      const size_t lds = std::max(cp.lds_bytes, fix_lds);
+      if ((rc = set_dyn_lds(ctx, k_customers_fused, lds))) return rc;
+      // as many leading workgroups as there are CUs the customer pass leaves idle (8 .. 64)
+      fa.lead = std::max(8, std::min(64, (ctx->n_cu - cp.blocks) / 8 * 8));
+      hipLaunchKernelGGL(k_customers_fused, dim3(cp.blocks + fa.lead), dim3(cp.threads), lds, st, fa);
+    } else if (cp.lds_tables && d_state) {
       if ((rc = set_dyn_lds(ctx, k_customers<true, true>, cp.lds_bytes))) return rc;
       hipLaunchKernelGGL((k_customers<true, true>), dim3(cp.blocks), dim3(cp.threads), cp.lds_bytes, st, c);
     } else if (cp.lds_tables) {
@@ -481,7 +509,15 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
-    if (cp.lds_tables) {
+    if (fused) {
+      TailArgs t;
+      t.m.cust_slab = ctx->d_cust_slab.p; t.m.n_streams = cp.n_streams; t.m.c_pad = cp.c_pad;
+      t.m.n_customers = n_customers; t.m.cust_carry = ctx->d_cust_carry.p; t.m.customer_total = d_ct;
+      t.f = f;
+      t.n_cust_blocks = (n_customers + 255) / 256;
+      t.n_prod_blocks = 0;          // the leading workgroups of the fused launch merged the stock deltas
+      hipLaunchKernelGGL(k_tail, dim3(t.n_cust_blocks + t.n_prod_blocks + (f.n_rec + 255) / 256), dim3(256), 0, st, t);
+    } else if (cp.lds_tables) {
       CustMergeArgs m;
       m.cust_slab = ctx->d_cust_slab.p; m.n_streams = cp.n_streams; m.c_pad = cp.c_pad;
       m.n_customers = n_customers; m.cust_carry = ctx->d_cust_carry.p; m.customer_total = d_ct;
@@ -564,6 +600,7 @@ ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
   ctx->k1_blocks_per_cu = std::max(1, env_int("ACMPC_K1_BPC", 1));
   ctx->k1_lpl = env_int("ACMPC_K1_LPL", 4);
   ctx->k2_threads = env_int("ACMPC_K2_THREADS", 1024);
+  ctx->fuse = env_int("ACMPC_FUSE", 1);
   ctx->k1_cus = env_int("ACMPC_K1_CUS", 0);
   ctx->k2_cus = env_int("ACMPC_K2_CUS", 0);
   if (ctx->k2_threads != 256 && ctx->k2_threads != 512 && ctx->k2_threads != 1024) ctx->k2_threads = 1024;
@@ -590,6 +627,7 @@ ACMPC_API void acmpc_destroy(acmpc_ctx* ctx) {
   release(ctx->s_order_id); release(ctx->s_product_idx); release(ctx->s_qty); release(ctx->s_order_customer);
   release(ctx->s_order_total); release(ctx->s_product_qty); release(ctx->s_customer_total);
   release(ctx->s_synth_off); release(ctx->s_synth_cdf);
+  release(ctx->d_edge_idx); release(ctx->d_edge_total);
   release(ctx->d_dict); release(ctx->d_dict_disp); release(ctx->d_codes); release(ctx->d_chunk_rows); release(ctx->d_ing_tables);
   release(ctx->s_text); release(ctx->d_chunk_bytes); release(ctx->s_emit_value);
   release(ctx->s_line_price); release(ctx->s_order_state); release(ctx->s_order_descuento);

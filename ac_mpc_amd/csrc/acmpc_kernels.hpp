@@ -66,6 +66,10 @@ struct LinesArgs {
   // unsorted, and redo the order totals only (stock deltas do not depend on the row order)
   int32_t only_if_unsorted;
   int32_t totals_only;
+  // k_lines: 1 = every wave also zeroes the totals of the orders without lines that lie between the
+  // previous wave's last order and its own first one (the first wave: before its first order; the last
+  // wave: after its last order).  Then no later kernel has to write zeros before the totals are read.
+  int32_t fill_edges;
   const unsigned char* order_state;   // [M] bit 0: the order counts towards stock and customer sums
 };
 
@@ -508,6 +512,11 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
       if (o.first_open) { a.rec_sum[2 * g] = o.sum; a.rec_sum[2 * g + 1] = 0; }
       else              { a.rec_sum[2 * g] = o.head_sum; a.rec_sum[2 * g + 1] = o.sum; }
     }
+    if (a.fill_edges) {
+      const int before = t0 == 0 ? a.base - 1 : a.order_id[t0 * kTileL - 1];   // last order of the wave before
+      wave_fill_gap(a, before, head_id, lane);
+      if (t1 == a.n_tiles) wave_fill_gap(a, o.id, a.base + a.n_orders, lane);
+    }
     if (o.st) atomicOr(a.status, o.st);
   }
 
@@ -686,6 +695,17 @@ struct FixArgs {
   unsigned long long* prod_carry;
   int64_t* product_qty;
   int32_t ablate;           // developer switch for timing experiments: 1 skip merge blocks, 2 skip block 0
+  // Deferred mode (the record block runs beside the customer pass instead of before it).  The customer
+  // pass then reads, for an order cut by a wave boundary, whatever k_lines left in its slot; this block
+  // reads the same word, adds (total - that word) to the customer's 64-bit cell — exact modulo 2^64,
+  // whatever the word was — and leaves (index, total) in the edge list; the slot itself is written after
+  // the customer pass, by k_tail.  Orders without lines were zeroed by k_lines (fill_edges).
+  int32_t deferred;
+  const int32_t* order_customer;
+  unsigned long long* cust_carry;
+  int32_t n_customers;
+  uint32_t* edge_idx;       // [n_rec] order index, or 0xffffffff
+  int64_t* edge_total;      // [n_rec]
 };
 
 __device__ __forceinline__ void block_fill_zero(int64_t* out, long long lo, long long hi, int n_orders) {
@@ -694,33 +714,54 @@ __device__ __forceinline__ void block_fill_zero(int64_t* out, long long lo, long
   for (long long k = lo + threadIdx.x; k < hi; k += blockDim.x) out[k] = 0;
 }
 
+// Stock-delta merge of one group of 64 products by a workgroup of `waves` waves: wave w sums slabs
+// w, w + waves, ...; s_part holds waves * 64 partial sums.
+__device__ __forceinline__ void merge_product_group(const FixArgs& a, int group, int waves, unsigned long long* s_part) {
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  const int p = group * kMergeProducts + lane;
+  unsigned long long acc = 0;
+  if (p < a.n_products) {
+    // sixteen independent loads per round: the loop is bound by latency, not by bytes
+    for (int s0 = wave; s0 < a.n_slabs; s0 += 16 * waves) {
+      uint32_t u[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int sj = s0 + j * waves;
+        u[j] = sj < a.n_slabs ? a.prod_slab[(size_t)sj * a.p_pad + p] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc += u[j];
+    }
+  }
+  s_part[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (wave == 0 && p < a.n_products) {
+    unsigned long long sum = a.prod_carry[p];
+    for (int w = 0; w < waves; ++w) sum += s_part[w * 64 + lane];
+    a.product_qty[p] = (int64_t)sum;
+    a.prod_carry[p] = 0ull;           // leave the workspace clean for the next call
+  }
+}
+
+__device__ __forceinline__ void fixup_records(const FixArgs& a, unsigned char* smem);
+
 __global__ void __launch_bounds__(kFixThreads) k_fixup(FixArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (blockIdx.x > 0) {
+    // ---- stock-delta merge: 64 products per block
+    if (!a.merge_products || (a.ablate & 1)) return;
+    merge_product_group(a, (int)blockIdx.x - 1, kFixThreads / 64, reinterpret_cast<unsigned long long*>(smem));
+    return;
+  }
+  if ((a.ablate & 2) || !a.fix_orders) return;
+  fixup_records(a, smem);
+}
+
+// One workgroup of kFixThreads threads; smem: kFixThreads * kFixStrip * 12 bytes.
+__device__ __forceinline__ void fixup_records(const FixArgs& a, unsigned char* smem) {
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-
-  if (blockIdx.x > 0) {
-    // ---- stock-delta merge: 64 products per block, wave w sums slabs w, w+16, ...
-    if (!a.merge_products || (a.ablate & 1)) return;
-    unsigned long long* s_part = reinterpret_cast<unsigned long long*>(smem);   // [16][64]
-    const int p = ((int)blockIdx.x - 1) * kMergeProducts + lane;
-    unsigned long long acc = 0;
-    if (p < a.n_products)
-      for (int s = wave; s < a.n_slabs; s += kFixThreads / 64) acc += a.prod_slab[(size_t)s * a.p_pad + p];
-    s_part[wave * 64 + lane] = acc;
-    __syncthreads();
-    if (wave == 0 && p < a.n_products) {
-      unsigned long long sum = a.prod_carry[p];
-#pragma unroll
-      for (int w = 0; w < kFixThreads / 64; ++w) sum += s_part[w * 64 + lane];
-      a.product_qty[p] = (int64_t)sum;
-      a.prod_carry[p] = 0ull;           // leave the workspace clean for the next call
-    }
-    return;
-  }
-
-  if ((a.ablate & 2) || !a.fix_orders) return;
   // ---- block 0: orders cut by wave boundaries.  Records are (order id, partial sum), two per
   // wave, in line order, hence sorted by id.  Every maximal run of equal ids is one order.
   long long* s_excl = reinterpret_cast<long long*>(smem);                       // [n_rec]
@@ -790,17 +831,27 @@ __global__ void __launch_bounds__(kFixThreads) k_fixup(FixArgs a) {
   for (int k = 0; k < kFixStrip; ++k) {
     const int i = i0 + k;
     if (i < n) {
+      if (a.deferred) a.edge_idx[i] = 0xffffffffu;              // overwritten below by a run's last record
       const int next_id = (i + 1 < n) ? ((k + 1 < kFixStrip) ? ids[(k + 1) % kFixStrip] : after_id) : 0;
       const bool tail = (i + 1 == n) || (next_id != ids[k]);
       if (tail) {
         const long long total = s_excl[i] + sums[k] - s_excl[s_head[i]];
         const uint32_t idx = (uint32_t)ids[k] - (uint32_t)a.base;
-        if (idx < (uint32_t)a.n_orders) a.order_total[idx] = total; else st |= kStOrderRange;
+        if (idx >= (uint32_t)a.n_orders) st |= kStOrderRange;
+        else if (!a.deferred) a.order_total[idx] = total;
+        else {
+          const long long seen = a.order_total[idx];           // what the customer pass reads for this order
+          const int32_t c = a.order_customer[idx];
+          if ((uint32_t)c < (uint32_t)a.n_customers)             // out of range: flagged by the customer pass
+            atomicAdd(&a.cust_carry[c], (unsigned long long)total - (unsigned long long)seen);
+          a.edge_idx[i] = idx;
+          a.edge_total[i] = total;
+        }
         // Only the step from a wave's tail record (odd i) to the next wave's head record can hide
         // orders without lines; between a wave's own head and tail k_lines wrote everything.
         if (i + 1 < n && (i & 1)) {
           if (next_id < ids[k]) st |= kStUnsorted;
-          else if ((uint32_t)next_id - (uint32_t)ids[k] > 1u) {
+          else if (!a.deferred && (uint32_t)next_id - (uint32_t)ids[k] > 1u) {
             const int slot = atomicAdd(&s_gap_n, 1);
             if (slot < 256) { s_gap_lo[slot] = ids[k]; s_gap_hi[slot] = next_id; }
             else {
@@ -820,7 +871,7 @@ __global__ void __launch_bounds__(kFixThreads) k_fixup(FixArgs a) {
     block_fill_zero(a.order_total, (long long)s_gap_lo[gidx] + 1 - a.base, (long long)s_gap_hi[gidx] - a.base,
                     a.n_orders);
   // orders before the first and after the last line
-  if (n > 0) {
+  if (n > 0 && !a.deferred) {
     block_fill_zero(a.order_total, 0, (long long)first_id - a.base, a.n_orders);
     block_fill_zero(a.order_total, (long long)last_id + 1 - a.base, a.n_orders, a.n_orders);
   }
@@ -899,15 +950,48 @@ __device__ __forceinline__ void customers_tile(const CustArgs& a, uint32_t* s_ta
 // Workgroup b: XCD label x = b % 8 (workgroups with equal label share an L2), slot j = b / 8,
 // range r = j % R, stream s = x + 8 * (j / R).  The R siblings of a stream read the same orders:
 // one of them brings a line in from HBM, the others find it in their XCD's L2.
+template <bool kLdsTables, bool kLife>
+__device__ __forceinline__ void customers_block(const CustArgs& a, unsigned char* smem, int bid);
+
 template <bool kLdsTables, bool kLife = false>
 __global__ void __launch_bounds__(1024) k_customers(CustArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
+  customers_block<kLdsTables, kLife>(a, smem, (int)blockIdx.x);
+}
+
+// The customer pass with the record block of k_fixup riding along: workgroup 0 finishes the orders cut
+// by wave boundaries in deferred mode (see FixArgs), workgroups 1..lead-1 merge the stock-delta slabs,
+// and workgroup lead + b is customer workgroup b (the customer pass maps workgroups to XCDs by index
+// modulo 8, so lead is a multiple of 8).
+struct CustFusedArgs {
+  CustArgs c;
+  FixArgs f;
+  int32_t lead;             // leading workgroups (a multiple of 8): one record block, lead - 1 merge blocks
+};
+
+__global__ void __launch_bounds__(1024) k_customers_fused(CustFusedArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  if ((int)blockIdx.x < a.lead) {
+    if (blockIdx.x == 0) { fixup_records(a.f, smem); return; }
+    // the other leading workgroups share the stock-delta merge (64 products per step)
+    const int n_groups = (a.f.n_products + kMergeProducts - 1) / kMergeProducts;
+    for (int g = (int)blockIdx.x - 1; g < n_groups; g += a.lead - 1) {
+      merge_product_group(a.f, g, (int)(blockDim.x >> 6), reinterpret_cast<unsigned long long*>(smem));
+      __syncthreads();
+    }
+    return;
+  }
+  customers_block<true, false>(a.c, smem, (int)blockIdx.x - a.lead);
+}
+
+template <bool kLdsTables, bool kLife>
+__device__ __forceinline__ void customers_block(const CustArgs& a, unsigned char* smem, int bid) {
   uint32_t* s_tab = reinterpret_cast<uint32_t*>(smem);
   uint32_t* s_dummy = s_tab + a.span;
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
   const int waves_per_block = (int)(blockDim.x >> 6);
-  const int x = (int)(blockIdx.x & 7), jslot = (int)(blockIdx.x >> 3);
+  const int x = bid & 7, jslot = bid >> 3;
   const int r = jslot % a.n_ranges;
   const int s = x + 8 * (jslot / a.n_ranges);
   const int lo = r * a.span;
@@ -1014,10 +1098,16 @@ struct CustMergeArgs {
 
 // 256 threads = 4 waves; the block owns 256 consecutive customers (4 per lane, 16-byte loads) and
 // wave w sums streams w, w+4, ...; the four partial sums meet in LDS.
+__device__ __forceinline__ void custmerge_block(const CustMergeArgs& a, int bid, unsigned long long (*s_part)[256]);
+
 __global__ void __launch_bounds__(256) k_custmerge(CustMergeArgs a) {
   __shared__ unsigned long long s_part[4][256];
+  custmerge_block(a, (int)blockIdx.x, s_part);
+}
+
+__device__ __forceinline__ void custmerge_block(const CustMergeArgs& a, int bid, unsigned long long (*s_part)[256]) {
   const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
-  const int c0 = (int)blockIdx.x * 256 + lane * 4;
+  const int c0 = bid * 256 + lane * 4;
   unsigned long long acc[4] = {0, 0, 0, 0};
   if (c0 < a.c_pad) {
 #pragma unroll 4
@@ -1029,7 +1119,7 @@ __global__ void __launch_bounds__(256) k_custmerge(CustMergeArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) s_part[wave][lane * 4 + i] = acc[i];
   __syncthreads();
-  const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  const int c = bid * 256 + (int)threadIdx.x;
   if (c < a.n_customers) {
     const unsigned long long sum = a.cust_carry[c] + s_part[0][threadIdx.x] + s_part[1][threadIdx.x] +
                                    s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
@@ -1055,6 +1145,32 @@ __global__ void __launch_bounds__(256) k_order_adjust(int64_t* order_total, cons
   if (o < n_orders) {
     const long long g = order_total[o];
     order_total[o] = (int64_t)((unsigned long long)g - (unsigned long long)descuento_cents(g, descuento[o], mode));
+  }
+}
+
+// Everything that is left after the fused customer pass, in one launch of 256-thread workgroups:
+//   [0, n_cust_blocks)                       customer merge (k_custmerge's work)
+//   [n_cust_blocks, + n_prod_blocks)         stock-delta merge, 64 products per workgroup
+//   the last ceil(n_rec / 256) workgroups    totals of the orders cut by wave boundaries -> order_total
+struct TailArgs {
+  CustMergeArgs m;
+  FixArgs f;
+  int32_t n_cust_blocks, n_prod_blocks;
+};
+
+__global__ void __launch_bounds__(256) k_tail(TailArgs a) {
+  __shared__ unsigned long long s_part[4][256];
+  const int b = (int)blockIdx.x;
+  if (b < a.n_cust_blocks) { custmerge_block(a.m, b, s_part); return; }
+  if (b < a.n_cust_blocks + a.n_prod_blocks) {             // (n_prod_blocks is 0 when the merge ran earlier)
+    merge_product_group(a.f, b - a.n_cust_blocks, 4, &s_part[0][0]);
+    return;
+  }
+  const int i = (b - a.n_cust_blocks - a.n_prod_blocks) * 256 + (int)threadIdx.x;
+  if (i < a.f.n_rec) {
+    const uint32_t idx = a.f.edge_idx[i];
+    const int64_t total = a.f.edge_total[i];
+    if (idx != 0xffffffffu) a.f.order_total[idx] = total;
   }
 }
 

@@ -15,6 +15,25 @@ from oracle import checkout_oracle as co
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["default", "fused"])
+def motor(request):
+    """Every parity case runs twice: with the library's own choice of launch sequence, and with the fused
+    three-launch sequence forced (by default it is only taken from a few million orders on)."""
+    from ac_mpc_amd import MotorLote
+    old = os.environ.get("ACMPC_FUSE")
+    if request.param == "fused":
+        os.environ["ACMPC_FUSE"] = "2"
+    try:
+        m = MotorLote(0)
+    finally:
+        if old is None:
+            os.environ.pop("ACMPC_FUSE", None)
+        else:
+            os.environ["ACMPC_FUSE"] = old
+    yield m
+    m.cerrar()
+
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 VECTORS = sorted(glob.glob(os.path.join(GOLDEN, "synth_*.npz")))
 
