@@ -88,6 +88,9 @@ struct acmpc_ctx {
   int k1_lpl = 4;
   int k2_threads = 1024;
   int k1_cus = 0, k2_cus = 0;   // developer switches: pretend the device has this many CUs (0 = all)
+  // developer switches for timing experiments: parts of a kernel are skipped and its results are WRONG.
+  // Read once at init, and only when ACMPC_DEV_ABLATE=1 is set as well.
+  int ablate_fix = 0, ablate_k2 = 0, ablate_ing = 0;
   int force_global_tables = 0;
   int line_order = ACMPC_ORDER_GROUPED;
 
@@ -421,7 +424,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     f.merge_products = lp.lds_tables ? 1 : 0;
     f.fix_orders = any_order ? 0 : 1;
     f.prod_carry = ctx->d_prod_carry.p; f.product_qty = d_pq;
-    f.ablate = env_int("ACMPC_FIX_ABLATE", 0);
+    f.ablate = ctx->ablate_fix;
     if (!fused) {
       if ((rc = set_dyn_lds(ctx, k_fixup, fix_lds))) return rc;
       const int fix_blocks = 1 + (lp.lds_tables ? (P + kMergeProducts - 1) / kMergeProducts : 0);
@@ -479,7 +482,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     c.n_customers = n_customers; c.c_pad = cp.c_pad; c.span = cp.span; c.n_ranges = cp.n_ranges;
     c.n_streams = cp.n_streams; c.cust_slab = ctx->d_cust_slab.p; c.cust_carry = ctx->d_cust_carry.p;
     c.status = ctx->d_status;
-    c.ablate = env_int("ACMPC_K2_ABLATE", 0);
+    c.ablate = ctx->ablate_k2;
     c.order_state = d_state;
     ctx->carry_dirty = true;
     if (fused) {
@@ -601,6 +604,11 @@ ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
   ctx->k1_lpl = env_int("ACMPC_K1_LPL", 4);
   ctx->k2_threads = env_int("ACMPC_K2_THREADS", 1024);
   ctx->fuse = env_int("ACMPC_FUSE", 1);
+  if (env_int("ACMPC_DEV_ABLATE", 0) == 1) {
+    ctx->ablate_fix = env_int("ACMPC_FIX_ABLATE", 0);
+    ctx->ablate_k2 = env_int("ACMPC_K2_ABLATE", 0);
+    ctx->ablate_ing = env_int("ACMPC_ING_ABLATE", 0);
+  }
   ctx->k1_cus = env_int("ACMPC_K1_CUS", 0);
   ctx->k2_cus = env_int("ACMPC_K2_CUS", 0);
   if (ctx->k2_threads != 256 && ctx->k2_threads != 512 && ctx->k2_threads != 1024) ctx->k2_threads = 1024;
@@ -1014,7 +1022,7 @@ ACMPC_API int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, in
   a.dict_seed = ctx->dict_seed; a.dict_bucket_shift = ctx->dict_bucket_shift;
   a.codes = ctx->d_codes.p;
   a.tables = ctx->d_ing_tables.p;
-  a.ablate = env_int("ACMPC_ING_ABLATE", 0);
+  a.ablate = ctx->ablate_ing;
   a.order_id = d_order_id; a.product_idx = d_product_idx; a.qty = d_qty; a.capacity = capacity_rows;
   a.n_rows = reinterpret_cast<long long*>(d_n_rows);
   a.n_malformed = reinterpret_cast<unsigned long long*>(ctx->d_ing_scalars + 1);
