@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the whole hot path (order-line kernel, fix-up, customer kernel, merge, and for
+A step is one pass of the whole hot path (order-line kernel, customer kernel with the fix-up of the
+orders cut by wave boundaries riding along, merge; below 4 M orders the fix-up is a launch of its own; for
 N > 1 the single all-reduce of the stock-delta and customer vectors) over one batch of synthetic
 store.sql-schema order lines that already sits in HBM.  Every rank owns a contiguous order-id range of
 one global data set of N x lines-per-gpu lines (weak scaling).  Rank 0 prints ONE JSON line.
@@ -23,6 +24,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E vendor peak (8 TB/s)
+# What this part delivers to a kernel that does nothing but move k_lines' bytes with k_lines' address
+# mapping (tools/stream_probe.hip: three columns read with streaming loads and one 8-byte store per four
+# lines, 0.257 ms for 1.4 GB).  Quoted beside the vendor peak; never used as `peak`.
+ACHIEVABLE_SAME_TRAFFIC_GBS = 5450.0
 
 
 def parse():
@@ -216,6 +221,9 @@ def main():
                 "other_kernels_ms": {k: v for k, v in k_ms.items() if k != "lines"},
                 "whole_step_algorithmic_GBs": (12 * ds.n_lines + 12 * ds.n_orders + 16 * P + 8 * Cn)
                 / (elapsed / args.steps) / 1e9,
+                "achievable_same_traffic_GBs": ACHIEVABLE_SAME_TRAFFIC_GBS,
+                "frac_of_achievable": achieved / ACHIEVABLE_SAME_TRAFFIC_GBS,
+                "launches_per_step": 3 if ds.n_orders >= 4_000_000 else 4,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
