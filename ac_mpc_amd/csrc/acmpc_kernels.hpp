@@ -155,8 +155,9 @@ __device__ __forceinline__ void split_add64(uint32_t* lds_lo, unsigned long long
 }
 
 // Zero order_total for the order ids strictly between a and b (exclusive), all 64 lanes helping.
-__device__ __forceinline__ void wave_fill_gap(const LinesArgs& a, int ida, int idb, int lane) {
-  for (long long k = (long long)ida + 1 + lane; k < (long long)idb; k += kWave) {
+// (64-bit bounds: base - 1 and base + n_orders may lie outside int32.)
+__device__ __forceinline__ void wave_fill_gap(const LinesArgs& a, long long ida, long long idb, int lane) {
+  for (long long k = ida + 1 + lane; k < idb; k += kWave) {
     const uint32_t idx = (uint32_t)((int)k) - (uint32_t)a.base;
     if (idx < (uint32_t)a.n_orders) a.order_total[idx] = 0;
   }
@@ -513,9 +514,9 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
       else              { a.rec_sum[2 * g] = o.head_sum; a.rec_sum[2 * g + 1] = o.sum; }
     }
     if (a.fill_edges) {
-      const int before = t0 == 0 ? a.base - 1 : a.order_id[t0 * kTileL - 1];   // last order of the wave before
-      wave_fill_gap(a, before, head_id, lane);
-      if (t1 == a.n_tiles) wave_fill_gap(a, o.id, a.base + a.n_orders, lane);
+      const long long before = t0 == 0 ? (long long)a.base - 1 : (long long)a.order_id[t0 * kTileL - 1];
+      wave_fill_gap(a, before, head_id, lane);                // behind the last order of the wave before
+      if (t1 == a.n_tiles) wave_fill_gap(a, o.id, (long long)a.base + a.n_orders, lane);
     }
     if (o.st) atomicOr(a.status, o.st);
   }
