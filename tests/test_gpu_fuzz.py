@@ -89,3 +89,91 @@ def test_random_small_inputs(oracle, fuse, order):
         for g, e, name in zip(got, exp[:3], ("order_total", "product_qty", "customer_total")):
             assert np.array_equal(g, e), (trial, name, fuse, order, oid.size, k["cust"].size)
     m.cerrar()
+
+
+@pytest.mark.parametrize("fuse", ["1", "2"])
+def test_random_medium_inputs_with_poisoned_outputs(oracle, fuse):
+    """Up to a few million lines over many waves and workgroups; the device outputs are filled with a
+    poison pattern before every call, so a slot the kernels forget to write cannot pass by luck."""
+    import torch
+    from ac_mpc_amd import MotorLote
+    old = os.environ.get("ACMPC_FUSE")
+    os.environ["ACMPC_FUSE"] = fuse
+    try:
+        m = MotorLote(0)
+    finally:
+        if old is None:
+            os.environ.pop("ACMPC_FUSE", None)
+        else:
+            os.environ["ACMPC_FUSE"] = old
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77 + int(fuse))
+    for trial in range(24):
+        n_lines = int(rng.choice([1, 255, 256, 257, 4096, 65_536, 300_001, 1_048_576, 3_000_000]))
+        density = rng.choice([0.02, 0.25, 1.0, 30.0])            # orders per line
+        n_orders = max(1, int(n_lines * density) + int(rng.integers(0, 50)))
+        base = int(rng.choice([5, -2_147_483_648, 2_147_483_647 - n_orders, 0]))
+        lo = int(rng.integers(0, max(1, n_orders // 3)))         # orders before `lo` and from `hi` on have no lines
+        hi = n_orders - int(rng.integers(0, max(1, n_orders // 3)))
+        hi = max(hi, lo + 1)
+        oid = (np.sort(rng.integers(lo, hi, size=n_lines)) + base).astype(np.int32)
+        p = int(rng.choice([3, 1000, 10_000, 70_000]))
+        c = int(rng.choice([1, 500, 100_000, 600_000]))
+        pidx = rng.integers(-1, p + 1, size=n_lines).astype(np.int32)
+        qty = (np.ones(n_lines) if rng.random() < 0.5 else rng.integers(-3, 100_000, size=n_lines)).astype(np.int32)
+        price = rng.integers(1, 500_000, size=p).astype(np.int64)
+        cust = rng.integers(0, c, size=n_orders).astype(np.int32)
+        m.cargar_productos(price)
+        t = [torch.from_numpy(x).to(dev) for x in (oid, pidx, qty, cust)]
+        poison = -0x2152_4111_2152_4111
+        tot = torch.full((n_orders,), poison, dtype=torch.int64, device=dev)
+        pq = torch.full((p,), poison, dtype=torch.int64, device=dev)
+        ct = torch.full((c,), poison, dtype=torch.int64, device=dev)
+        m.agregar_device(t[0], t[1], t[2], t[3], base, c, tot, pq, ct)
+        assert m.estado() == 0
+        etot, epq, ect, flags = oracle.aggregate(oid, pidx, qty, cust, base, c, price)
+        assert flags == 0
+        for g, e, name in zip((tot, pq, ct), (etot, epq, ect), ("order_total", "product_qty", "customer_total")):
+            assert np.array_equal(g.cpu().numpy(), e), (trial, name, fuse, n_lines, n_orders, p, c, base)
+    m.cerrar()
+
+
+def test_text_paths_with_poisoned_device_buffers(oracle):
+    """Ingest and emit through their device entry points into poisoned buffers, several calls on one context."""
+    import torch
+    from ac_mpc_amd import MotorLote, emision, ingesta
+    from tests import ingest_cases as ic
+    m = MotorLote(0)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(91)
+    p = 500
+    codes = [ic.code_of(i) for i in range(p)]
+    ingesta.cargar_codigos(m, codes)
+    for trial in range(12):
+        n = int(rng.choice([0, 1, 700, 20_000, 250_000]))
+        oid = np.sort(rng.integers(5, 5 + max(1, n // 3), size=n)).astype(np.int32)
+        pidx = rng.integers(-1, p, size=n).astype(np.int32)
+        qty = rng.integers(-9, 10_000, size=n).astype(np.int32)
+        style = str(rng.choice(["dump", "csv", "tsv_crlf", "quoted"]))
+        text = ic.render(oid.tolist(), pidx.tolist(), qty.tolist(), style) if n else b"-- nothing\n"
+        tb = torch.frombuffer(bytearray(text + b"\0" * 16), dtype=torch.uint8).to(dev)[: len(text)]
+        cap = n + 5
+        cols = [torch.full((cap,), -77, dtype=torch.int32, device=dev) for _ in range(3)]
+        cnt = torch.full((1,), -1, dtype=torch.int64, device=dev)
+        ingesta.leer_detalle_device(m, tb, cols[0], cols[1], cols[2], cnt)
+        assert m.estado() == 0 and int(cnt.item()) == n
+        for got, exp in zip(cols, (oid, pidx, qty)):
+            assert np.array_equal(got[:n].cpu().numpy(), exp)
+            assert bool((got[n:] == -77).all())                       # nothing written past the rows
+        # emit the totals of a random vector into a poisoned text buffer
+        mo = int(rng.choice([1, 300, 5000, 70_000]))
+        tot = rng.integers(-10**7, 10**12, size=mo).astype(np.int64)
+        st = int(rng.integers(0, 2))
+        exp_text = oracle.emit_totals(tot, 5, st)
+        out = torch.full((len(exp_text) + 64,), 0x7e, dtype=torch.uint8, device=dev)
+        nb = torch.full((1,), -1, dtype=torch.int64, device=dev)
+        emision.totales_device(m, torch.from_numpy(tot).to(dev), 5, st, out, nb)
+        assert m.estado() == 0 and int(nb.item()) == len(exp_text)
+        got_text = bytes(out.cpu().numpy())
+        assert got_text[: len(exp_text)] == exp_text and got_text[len(exp_text):] == b"\x7e" * 64
+    m.cerrar()
