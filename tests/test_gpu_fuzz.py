@@ -108,10 +108,10 @@ def test_random_medium_inputs_with_poisoned_outputs(oracle, fuse):
             os.environ["ACMPC_FUSE"] = old
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(77 + int(fuse))
-    for trial in range(24):
+    for trial in range(30):
         n_lines = int(rng.choice([1, 255, 256, 257, 4096, 65_536, 300_001, 1_048_576, 3_000_000]))
         density = rng.choice([0.02, 0.25, 1.0, 30.0])            # orders per line
-        n_orders = max(1, int(n_lines * density) + int(rng.integers(0, 50)))
+        n_orders = min(8_000_000, max(1, int(n_lines * density) + int(rng.integers(0, 50))))
         base = int(rng.choice([5, -2_147_483_648, 2_147_483_647 - n_orders, 0]))
         lo = int(rng.integers(0, max(1, n_orders // 3)))         # orders before `lo` and from `hi` on have no lines
         hi = n_orders - int(rng.integers(0, max(1, n_orders // 3)))
@@ -124,17 +124,35 @@ def test_random_medium_inputs_with_poisoned_outputs(oracle, fuse):
         price = rng.integers(1, 500_000, size=p).astype(np.int64)
         cust = rng.integers(0, c, size=n_orders).astype(np.int32)
         m.cargar_productos(price)
+        # row order and lifecycle columns at random
+        order = [False, True, "auto"][int(rng.integers(0, 3))]
+        lp = rng.integers(1, 10**6, size=n_lines).astype(np.int64) if rng.random() < 0.3 else None
+        stt = rng.integers(0, 2, size=n_orders).astype(np.uint8) if rng.random() < 0.3 else None
+        de = rng.integers(0, 101, size=n_orders).astype(np.int32) if rng.random() < 0.3 else None
+        pct = bool(rng.integers(0, 2))
+        if order is not False and n_lines > 1:
+            perm = rng.permutation(n_lines) if rng.random() < 0.5 else np.arange(n_lines)
+            if rng.random() < 0.5:                                 # a single swapped pair, far apart
+                i, j = sorted(rng.integers(0, n_lines, size=2).tolist())
+                perm[i], perm[j] = perm[j], perm[i]
+            oid, pidx, qty = oid[perm], pidx[perm], qty[perm]
+            lp = None if lp is None else lp[perm]
+        m.orden_lineas(order)
         t = [torch.from_numpy(x).to(dev) for x in (oid, pidx, qty, cust)]
+        life = dict(precio_linea=None if lp is None else torch.from_numpy(lp).to(dev),
+                    estado_pedido=None if stt is None else torch.from_numpy(stt).to(dev),
+                    descuento=None if de is None else torch.from_numpy(de).to(dev), descuento_porcentaje=pct)
         poison = -0x2152_4111_2152_4111
         tot = torch.full((n_orders,), poison, dtype=torch.int64, device=dev)
         pq = torch.full((p,), poison, dtype=torch.int64, device=dev)
         ct = torch.full((c,), poison, dtype=torch.int64, device=dev)
-        m.agregar_device(t[0], t[1], t[2], t[3], base, c, tot, pq, ct)
+        m.agregar_device(t[0], t[1], t[2], t[3], base, c, tot, pq, ct, **life)
         assert m.estado() == 0
-        etot, epq, ect, flags = oracle.aggregate(oid, pidx, qty, cust, base, c, price)
-        assert flags == 0
+        etot, epq, ect, flags = oracle.aggregate_lifecycle(oid, pidx, qty, cust, base, c, price, lp, stt, de, int(pct))
+        assert flags & ~2 == 0
         for g, e, name in zip((tot, pq, ct), (etot, epq, ect), ("order_total", "product_qty", "customer_total")):
-            assert np.array_equal(g.cpu().numpy(), e), (trial, name, fuse, n_lines, n_orders, p, c, base)
+            assert np.array_equal(g.cpu().numpy(), e), (trial, name, fuse, order, n_lines, n_orders, p, c, base,
+                                                        lp is not None, stt is not None, de is not None)
     m.cerrar()
 
 
