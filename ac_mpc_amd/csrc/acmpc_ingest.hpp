@@ -332,22 +332,36 @@ __device__ __forceinline__ unsigned long long ing_digits_value(const unsigned ch
   return (unsigned long long)v[0] * 100000000ull + (unsigned long long)(v[1] * 10000u + v[2]);
 }
 
-// Parse the data row that starts at byte `p` of the LDS text.  Returns false when malformed.
-__device__ __forceinline__ bool ing_row(const unsigned char* s_text, const unsigned char* s_ct, const uint2* s_T, int p,
-                                        const IngestArgs& a, int32_t& oid, int32_t& pidx, int32_t& qty) {
-  uint32_t st16 = sStart * kNumClasses, A = 0, B = 0;
-  const unsigned char* row = s_text + p;
-  for (int j0 = 0; j0 < ((a.ablate & 4) ? 8 : kIngSteps); j0 += 8) {
+// Run the automaton over N rows of this lane at once (they start at bytes p[0..N) of the LDS text).  The
+// table look-ups of one row depend on each other; stepping several rows together fills the waits.
+template <int N>
+__device__ __forceinline__ void ing_scan_rows(const unsigned char* s_text, const unsigned char* s_ct, const uint2* s_T,
+                                              const int (&p)[N], uint32_t (&st16)[N], uint32_t (&A)[N], uint32_t (&B)[N]) {
+#pragma unroll
+  for (int q = 0; q < N; ++q) { st16[q] = sStart * kNumClasses; A[q] = 0; B[q] = 0; }
+  for (int j0 = 0; j0 < kIngSteps; j0 += 8) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const uint32_t cls = s_ct[row[j0 + j]];
-      const uint2 e = s_T[st16 + cls];
-      B += e.x;
-      A += e.y;
-      st16 = e.x >> kBState;
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        const uint32_t cls = s_ct[s_text[p[q] + j0 + j]];
+        const uint2 e = s_T[st16[q] + cls];
+        B[q] += e.x;
+        A[q] += e.y;
+        st16[q] = e.x >> kBState;
+      }
     }
-    if (__ballot(st16 < (uint32_t)(sDone * kNumClasses)) == 0ull) break;      // every active lane is done
+    bool running = false;
+#pragma unroll
+    for (int q = 0; q < N; ++q) running |= st16[q] < (uint32_t)(sDone * kNumClasses);
+    if (__ballot(running) == 0ull) break;                  // every row of every active lane is done
   }
+}
+
+// Turn the automaton's final state and counters for the row at byte `p` into the three columns.
+// Returns false when the row is malformed.
+__device__ __forceinline__ bool ing_finish_row(const unsigned char* s_text, int p, uint32_t st16, uint32_t A, uint32_t B,
+                                               const IngestArgs& a, int32_t& oid, int32_t& pidx, int32_t& qty) {
   const int nd1 = (A >> kANd1) & 127, nd2 = (A >> kANd2) & 127, cl = (A >> kACl) & 127, len = (A >> kALen) & 127;
   const bool neg1 = (A >> kANeg1) & 1u, neg2 = (A >> kANeg2) & 1u;
   const int e1 = (B >> kBE1) & 127, cs = (B >> kBCs) & 127, e2 = (B >> kBE2) & 127;
@@ -386,7 +400,7 @@ __device__ __forceinline__ bool ing_row(const unsigned char* s_text, const unsig
   return ok;
 }
 
-__global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
+__global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) k_ingest_parse(IngestArgs a) {
   // [16 bytes of slack][chunk][look-ahead][slack]: number and code windows may reach a few bytes outside a row
   __shared__ __align__(16) unsigned char s_text[kIngFront + kIngChunk + kIngLook + 64];
   // start offsets of the chunk's data rows, in text order (a data row takes at least two bytes)
@@ -488,11 +502,26 @@ __global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
     if (n_r <= kKeep) {
       // the row list needs n_r entries only; the rest of its space holds the parsed columns meanwhile
       int32_t* s_res = reinterpret_cast<int32_t*>(s_row + kKeep);
-      for (r = tid; r < n_r; r += kIngThreads) {
-        int32_t oid = 0, pidx = -1, qty = 0;
-        const bool ok = (a.ablate & 1) ? true : ing_row(s_text, s_ct, s_T, kIngFront + (int)s_row[r], a, oid, pidx, qty);
-        if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
-        s_res[r] = oid; s_res[kKeep + r] = pidx; s_res[2 * kKeep + r] = qty;
+      constexpr int kTogether = 1;                           // rows a thread steps through the automaton at once (2: no gain)
+      for (r = tid; r < n_r; r += kTogether * kIngThreads) {
+        int p[kTogether];
+        uint32_t st16[kTogether], A[kTogether], B[kTogether];
+#pragma unroll
+        for (int q = 0; q < kTogether; ++q) {                // a missing second row repeats the first
+          const int rq = r + q * kIngThreads;
+          p[q] = kIngFront + (int)s_row[rq < n_r ? rq : r];
+        }
+        ing_scan_rows<kTogether>(s_text, s_ct, s_T, p, st16, A, B);
+#pragma unroll
+        for (int q = 0; q < kTogether; ++q) {
+          const int rq = r + q * kIngThreads;
+          if (rq < n_r) {
+            int32_t oid = 0, pidx = -1, qty = 0;
+            const bool ok = (a.ablate & 1) ? true : ing_finish_row(s_text, p[q], st16[q], A[q], B[q], a, oid, pidx, qty);
+            if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
+            s_res[rq] = oid; s_res[kKeep + rq] = pidx; s_res[2 * kKeep + rq] = qty;
+          }
+        }
       }
       resolve_base();
       const long long rbase = s_base;
@@ -505,7 +534,10 @@ __global__ void __launch_bounds__(kIngThreads) k_ingest_parse(IngestArgs a) {
       const long long rbase = s_base;
       for (r = tid; r < n_r; r += kIngThreads) {
         int32_t oid = 0, pidx = -1, qty = 0;
-        const bool ok = ing_row(s_text, s_ct, s_T, kIngFront + (int)s_row[r], a, oid, pidx, qty);
+        const int p[1] = {kIngFront + (int)s_row[r]};
+        uint32_t st16[1], A[1], B[1];
+        ing_scan_rows<1>(s_text, s_ct, s_T, p, st16, A, B);
+        const bool ok = ing_finish_row(s_text, p[0], st16[0], A[0], B[0], a, oid, pidx, qty);
         if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
         const long long row = rbase + r;
         if (row < a.capacity) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }
