@@ -87,6 +87,7 @@ struct acmpc_ctx {
   int k1_blocks_per_cu = 1;
   int k1_lpl = 4;
   int k2_threads = 1024;
+  int k1_burst = 2;             // tiles between synchronised output bursts of k_lines (0 = off)
   int k1_cus = 0, k2_cus = 0;   // developer switches: pretend the device has this many CUs (0 = all)
   // developer switches for timing experiments: parts of a kernel are skipped and its results are WRONG.
   // Read once at init, and only when ACMPC_DEV_ABLATE=1 is set as well.
@@ -391,6 +392,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.only_if_unsorted = 0;
     a.totals_only = 0;
     a.fill_edges = fused ? 1 : 0;
+    a.burst = life_lines ? 0 : ctx->k1_burst;     // (measured: no gain with the lifecycle columns)
     a.order_state = d_state;
 
     ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
@@ -609,6 +611,7 @@ ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
     ctx->ablate_k2 = env_int("ACMPC_K2_ABLATE", 0);
     ctx->ablate_ing = env_int("ACMPC_ING_ABLATE", 0);
   }
+  ctx->k1_burst = std::max(0, env_int("ACMPC_K1_BURST", 2));
   ctx->k1_cus = env_int("ACMPC_K1_CUS", 0);
   ctx->k2_cus = env_int("ACMPC_K2_CUS", 0);
   if (ctx->k2_threads != 256 && ctx->k2_threads != 512 && ctx->k2_threads != 1024) ctx->k2_threads = 1024;

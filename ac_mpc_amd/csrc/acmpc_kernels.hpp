@@ -70,6 +70,10 @@ struct LinesArgs {
   // previous wave's last order and its own first one (the first wave: before its first order; the last
   // wave: after its last order).  Then no later kernel has to write zeros before the totals are read.
   int32_t fill_edges;
+  // k_lines: > 0 = the waves of a workgroup write their closed orders out together every `burst` tiles
+  // (a workgroup barrier, then every wave flushes): the memory system takes the order totals better in
+  // bursts than trickling in between the reads.  Only in workgroups whose waves all have full runs.
+  int32_t burst;
   const unsigned char* order_state;   // [M] bit 0: the order counts towards stock and customer sums
 };
 
@@ -454,6 +458,9 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
       load_lines<LPL>(a.product_idx + off, npr);
       load_lines<LPL>(a.qty + off, nq);
       if constexpr (kLife) { if (snapped) load_prices_raw(a.line_price + (off - lane * LPL), lane, nraw); }
+      const bool bursts = a.burst > 0 &&
+                          (long long)(blockIdx.x + 1) * waves_per_block * a.tiles_per_wave <= n_full;   // workgroup-uniform
+      int until_burst = a.burst;
       for (long long t = t0; t <= last; ++t) {
         int ids[LPL], prs[LPL], qs[LPL];
         long long sn[4];
@@ -472,6 +479,11 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
                                                     snapped ? sn : nullptr);
         } else {
           lines_tile<PriceT, kLdsTables, LPL>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs);
+        }
+        if (bursts && --until_burst == 0) {
+          until_burst = a.burst;
+          __syncthreads();
+          stage_flush(a, s_stage, o, min(((uint32_t)o.id - (uint32_t)a.base) - o.buf_base, a.stage_cap), lane);
         }
       }
     }
