@@ -253,7 +253,7 @@ int main(int argc, char** argv) {
   RUN(2, 1, 1, 256, 1024) RUN(2, 1, 2, 256, 1024) RUN(2, 1, 3, 256, 1024) RUN(2, 2, 2, 2048, 256)
   RUN(208, 1, 9, 256, 1024) RUN(216, 1, 9, 256, 1024) RUN(208, 1, 13, 256, 1024) RUN(216, 1, 13, 256, 1024) RUN(204, 1, 13, 256, 1024) RUN(202, 1, 13, 256, 1024) RUN(204, 1, 9, 256, 1024)
   RUN(104, 1, 9, 256, 1024) RUN(116, 1, 9, 256, 1024) RUN(164, 1, 9, 256, 1024) RUN(116, 1, 11, 256, 1024) RUN(164, 1, 11, 256, 1024) RUN(2, 2, 9, 256, 1024) RUN(2, 1, 9, 512, 1024) RUN(2, 1, 11, 256, 1024)
-  RUN(0, 1, 9, 256, 1024) RUN(0, 1, 10, 256, 1024) RUN(0, 1, 11, 256, 1024) RUN(0, 1, 12, 256, 1024) RUN(0, 2, 9, 256, 1024) RUN(0, 2, 10, 256, 1024) RUN(2, 1, 9, 256, 1024)
+  RUN(1, 1, 9, 256, 1024) RUN(1, 1, 11, 256, 1024) RUN(1, 2, 9, 256, 1024) RUN(0, 1, 9, 256, 1024) RUN(0, 1, 10, 256, 1024) RUN(0, 1, 11, 256, 1024) RUN(0, 1, 12, 256, 1024) RUN(0, 2, 9, 256, 1024) RUN(0, 2, 10, 256, 1024) RUN(2, 1, 9, 256, 1024)
   // write-only and copy calibration: 16 B per lane
   {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
