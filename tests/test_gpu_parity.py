@@ -277,7 +277,8 @@ def test_shards_merge_to_the_single_device_result(motor, oracle):
 
 @pytest.mark.parametrize("zipf", [0, 1])
 def test_full_size_100m_lines(motor, oracle, zipf):
-    """BASELINE config 3 (and the per-GPU share of configs 4/5): size-independent invariants, then the
+    """The benchmark's primary configuration, 100 M lines on one GPU (also the per-GPU share of the sharded
+    1 G-line configurations): size-independent invariants, then the
     C oracle itself on the same columns (it needs ~0.2 s for 100M lines)."""
     import torch
     n, p, c = 100_000_000, 10_000, 100_000
