@@ -144,7 +144,8 @@ __device__ __forceinline__ long long ing_row_base(unsigned long long* state, lon
 }
 
 // Two hashes of a product code given as its 32 NUL-padded bytes in eight little-endian 32-bit words.
-// `a` is a seeded multiplicative chain over the words, `b` an independent rotation fold; the dictionary
+// `a` is a seeded multiplicative chain over the first four words (codes that differ only past byte 16
+// are told apart by b), `b` an independent rotation fold over all eight; the dictionary
 // is a perfect hash built on them (hash-and-displace): bucket = top bits of a, and every bucket has a
 // displacement d such that slot = (a + d * (b | 1)) & mask is a slot of its own for each of its codes.
 struct IngHash { uint32_t a, b; };
@@ -152,7 +153,7 @@ __host__ __device__ __forceinline__ uint32_t ing_rotl(uint32_t x, int r) { retur
 __host__ __device__ __forceinline__ IngHash ing_code_hash(const uint32_t (&w)[8], uint32_t seed) {
   uint32_t a = 0x811C9DC5u ^ seed;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) a = (a ^ w[i]) * 0x01000193u;
+  for (int i = 0; i < 4; ++i) a = (a ^ w[i]) * 0x01000193u;
   a ^= a >> 15;
   a *= 0x85EBCA77u;
   a ^= a >> 13;
@@ -314,22 +315,27 @@ __device__ __forceinline__ uint32_t ing_four_digits(uint32_t y) {
   return (t & 0xffu) * 100u + ((t >> 16) & 0xffu);
 }
 
-// Value of the nd (1..10) decimal digits that end just before byte `pe` of the LDS text (pe >= 12).
+// Value of the nd decimal digits (nd <= 4 * W, W = 1..3 words) that end just before byte `pe` of the LDS
+// text (pe >= 4 * W).
+template <int W>
 __device__ __forceinline__ unsigned long long ing_digits_value(const unsigned char* s_text, int pe, int nd) {
-  const int p0 = pe - 12;
+  const int p0 = pe - 4 * W;
   const uint32_t* w = reinterpret_cast<const uint32_t*>(s_text) + (p0 >> 2);
   const uint32_t sh = (uint32_t)p0 & 3u;
-  const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3];
-  const uint32_t x[3] = {ing_alignbyte(d1, d0, sh), ing_alignbyte(d2, d1, sh), ing_alignbyte(d3, d2, sh)};
-  const int drop = 12 - nd;                       // bytes in front of the number (little endian: low bytes first)
-  uint32_t v[3];
+  uint32_t d[W + 1];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i <= W; ++i) d[i] = w[i];
+  const int drop = 4 * W - nd;                    // bytes in front of the number (little endian: low bytes first)
+  uint32_t v[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
     const int di = min(max(drop - 4 * i, 0), 4);
     const uint32_t mask = di >= 4 ? 0u : (0xffffffffu << (8 * di));
-    v[i] = ing_four_digits(x[i] & mask & 0x0f0f0f0fu);
+    v[i] = ing_four_digits(ing_alignbyte(d[i + 1], d[i], sh) & mask & 0x0f0f0f0fu);
   }
-  return (unsigned long long)v[0] * 100000000ull + (unsigned long long)(v[1] * 10000u + v[2]);
+  if (W == 1) return v[0];
+  if (W == 2) return v[0] * 10000u + v[W - 1];
+  return (unsigned long long)v[0] * 100000000ull + (unsigned long long)(v[W > 1 ? 1 : 0] * 10000u + v[W - 1]);
 }
 
 // Run the automaton over N rows of this lane at once (they start at bytes p[0..N) of the LDS text).  The
@@ -359,15 +365,18 @@ __device__ __forceinline__ void ing_scan_rows(const unsigned char* s_text, const
 }
 
 // Turn the automaton's final state and counters for the row at byte `p` into the three columns.
-// Returns false when the row is malformed.
+// Returns false when the row is malformed.  W1, W2: words of digits read for the two numbers; NC: words
+// of the code that are cut out (the rest are zero).  The caller picks <3, 3, 8>, which covers every row,
+// or a cheaper combination when no row of the wave needs more.
+template <int W1, int W2, int NC>
 __device__ __forceinline__ bool ing_finish_row(const unsigned char* s_text, int p, uint32_t st16, uint32_t A, uint32_t B,
                                                const IngestArgs& a, int32_t& oid, int32_t& pidx, int32_t& qty) {
   const int nd1 = (A >> kANd1) & 127, nd2 = (A >> kANd2) & 127, cl = (A >> kACl) & 127, len = (A >> kALen) & 127;
   const bool neg1 = (A >> kANeg1) & 1u, neg2 = (A >> kANeg2) & 1u;
   const int e1 = (B >> kBE1) & 127, cs = (B >> kBCs) & 127, e2 = (B >> kBE2) & 127;
   bool ok = st16 == (uint32_t)(sDone * kNumClasses) && len <= kIngMaxRow && nd1 <= 10 && nd2 <= 10 && cl <= 30;
-  const unsigned long long v1 = ing_digits_value(s_text, p + e1, min(nd1, 10));
-  const unsigned long long v2 = ing_digits_value(s_text, p + e2, min(nd2, 10));
+  const unsigned long long v1 = ing_digits_value<W1>(s_text, p + e1, min(nd1, W1 == 3 ? 10 : 4 * W1));
+  const unsigned long long v2 = ing_digits_value<W2>(s_text, p + e2, min(nd2, W2 == 3 ? 10 : 4 * W2));
   ok = ok && v1 <= (neg1 ? 2147483648ull : 2147483647ull) && v2 <= (neg2 ? 2147483648ull : 2147483647ull);
   oid = (int32_t)(neg1 ? 0u - (uint32_t)v1 : (uint32_t)v1);
   qty = (int32_t)(neg2 ? 0u - (uint32_t)v2 : (uint32_t)v2);
@@ -375,10 +384,10 @@ __device__ __forceinline__ bool ing_finish_row(const unsigned char* s_text, int 
   const int pc = p + cs;
   const uint32_t* w = reinterpret_cast<const uint32_t*>(s_text) + (pc >> 2);
   const uint32_t sh = (uint32_t)pc & 3u;
-  uint32_t cw[8];
+  uint32_t cw[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
   uint32_t lo = w[0];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const uint32_t hi = w[i + 1];
     const int keep = min(max(cl - 4 * i, 0), 4);
     const uint32_t mask = keep >= 4 ? 0xffffffffu : ((1u << (8 * keep)) - 1u);
@@ -517,7 +526,14 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
           const int rq = r + q * kIngThreads;
           if (rq < n_r) {
             int32_t oid = 0, pidx = -1, qty = 0;
-            const bool ok = (a.ablate & 1) ? true : ing_finish_row(s_text, p[q], st16[q], A[q], B[q], a, oid, pidx, qty);
+            // the cheaper conversion when no row of the wave has a long number or a long code
+            const uint32_t Aq = A[q];
+            const bool plain = ((Aq >> kANd1) & 127u) <= 8u && ((Aq >> kANd2) & 127u) <= 4u && ((Aq >> kACl) & 127u) <= 12u;
+            bool ok = true;
+            if (!(a.ablate & 1)) {
+              if (__ballot(!plain) == 0ull) ok = ing_finish_row<2, 1, 3>(s_text, p[q], st16[q], Aq, B[q], a, oid, pidx, qty);
+              else ok = ing_finish_row<3, 3, 8>(s_text, p[q], st16[q], Aq, B[q], a, oid, pidx, qty);
+            }
             if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
             s_res[rq] = oid; s_res[kKeep + rq] = pidx; s_res[2 * kKeep + rq] = qty;
           }
@@ -537,7 +553,7 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
         const int p[1] = {kIngFront + (int)s_row[r]};
         uint32_t st16[1], A[1], B[1];
         ing_scan_rows<1>(s_text, s_ct, s_T, p, st16, A, B);
-        const bool ok = ing_finish_row(s_text, p[0], st16[0], A[0], B[0], a, oid, pidx, qty);
+        const bool ok = ing_finish_row<3, 3, 8>(s_text, p[0], st16[0], A[0], B[0], a, oid, pidx, qty);
         if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
         const long long row = rbase + r;
         if (row < a.capacity) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }
