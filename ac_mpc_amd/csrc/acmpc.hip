@@ -21,6 +21,11 @@ namespace {
 
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kLdsReserve = 1024;       // static LDS some kernels declare besides the tables
+// Size limits that keep the padded counts, table sizes and chunk tickets inside 32 bits.
+constexpr int32_t kMaxProducts = 1 << 28;
+constexpr int32_t kMaxCodes = 1 << 24;
+constexpr int32_t kMaxCustomers = 1 << 30;
+constexpr int64_t kMaxTextBytes = 1ll << 44;
 
 char g_init_error[512] = "no error";
 
@@ -317,6 +322,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     return fail(ctx, ACMPC_E_INVALID, "negative size or n_customers <= 0");
   if (n_orders > 0x7fffffffll || n_lines > (1ll << 40))
     return fail(ctx, ACMPC_E_INVALID, "n_orders must fit int32 (order ids are INT, store.sql:98,159)");
+  if (n_customers > kMaxCustomers) return fail(ctx, ACMPC_E_INVALID, "more than %d customers", kMaxCustomers);
   if ((n_lines > 0 && (!d_order_id || !d_product_idx || !d_qty)) || (n_orders > 0 && (!d_order_customer || !d_tot)) ||
       !d_pq || !d_ct)
     return fail(ctx, ACMPC_E_INVALID, "null device pointer");
@@ -652,6 +658,7 @@ ACMPC_API void acmpc_destroy(acmpc_ctx* ctx) {
 ACMPC_API int acmpc_set_products(acmpc_ctx* ctx, const int64_t* price_cents, int32_t n_products) {
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_set_products: null context");
   if (!price_cents || n_products <= 0) return fail(ctx, ACMPC_E_INVALID, "acmpc_set_products: empty product table");
+  if (n_products > kMaxProducts) return fail(ctx, ACMPC_E_INVALID, "acmpc_set_products: more than %d products", kMaxProducts);
   ENTER_DEVICE(ctx);
   HIPCHK(ctx, hipDeviceSynchronize());          // nothing may still be reading the old table
   int rc = ensure(ctx, ctx->d_price, (size_t)n_products + 1);
@@ -730,6 +737,8 @@ ACMPC_API int acmpc_aggregate_lifecycle(acmpc_ctx* ctx, const int32_t* order_id,
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_aggregate: null context");
   if (ctx->n_products <= 0) return fail(ctx, ACMPC_E_STATE, "acmpc_set_products has not been called");
   if (n_lines < 0 || n_orders < 0 || n_customers <= 0) return fail(ctx, ACMPC_E_INVALID, "negative size or n_customers <= 0");
+  if (n_orders > 0x7fffffffll || n_lines > (1ll << 40) || n_customers > kMaxCustomers)
+    return fail(ctx, ACMPC_E_INVALID, "size beyond the limits (n_orders int32, n_lines 2^40, n_customers %d)", kMaxCustomers);
   if ((n_lines > 0 && (!order_id || !product_idx || !qty)) || (n_orders > 0 && (!order_customer || !out_order_total_cents)) ||
       !out_product_qty || !out_customer_total_cents)
     return fail(ctx, ACMPC_E_INVALID, "null host pointer");
@@ -889,6 +898,7 @@ ACMPC_API int acmpc_synth_generate_device(acmpc_ctx* ctx, const acmpc_synth_cfg*
 ACMPC_API int acmpc_set_product_codes(acmpc_ctx* ctx, const char* codes32, int32_t n_products) {
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_set_product_codes: null context");
   if (!codes32 || n_products <= 0) return fail(ctx, ACMPC_E_INVALID, "acmpc_set_product_codes: empty code list");
+  if (n_products > kMaxCodes) return fail(ctx, ACMPC_E_INVALID, "acmpc_set_product_codes: more than %d codes", kMaxCodes);
   ENTER_DEVICE(ctx);
   HIPCHK(ctx, hipDeviceSynchronize());
   uint32_t size = 16;
@@ -1008,6 +1018,7 @@ ACMPC_API int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, in
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_ingest_detalle_device: null context");
   if (ctx->dict_products <= 0) return fail(ctx, ACMPC_E_STATE, "acmpc_set_product_codes has not been called");
   if (n_bytes < 0 || capacity_rows < 0 || !d_n_rows) return fail(ctx, ACMPC_E_INVALID, "bad size or null row counter");
+  if (n_bytes > kMaxTextBytes) return fail(ctx, ACMPC_E_INVALID, "more than 2^44 bytes of text");
   if (n_bytes > 0 && !d_text) return fail(ctx, ACMPC_E_INVALID, "null text pointer");
   if (capacity_rows > 0 && (!d_order_id || !d_product_idx || !d_qty)) return fail(ctx, ACMPC_E_INVALID, "null column pointer");
   if (!aligned16(d_text)) return fail(ctx, ACMPC_E_ALIGN, "device text must be 16-byte aligned");

@@ -28,6 +28,10 @@
  *
  * Threading: one context is used by one thread at a time.  Many processes may
  * each hold their own context on the same GPU.
+ *
+ * Limits (larger counts return ACMPC_E_INVALID): n_orders < 2^31 (order ids are
+ * INT, store.sql:98,159), n_lines <= 2^40, n_products <= 2^28 (2^24 for a code
+ * list), n_customers <= 2^30, 2^44 bytes of text per ingest call.
  */
 #ifndef ACMPC_H
 #define ACMPC_H

@@ -224,6 +224,25 @@ def test_aggregate_before_products_is_a_state_error():
         m.cerrar()
 
 
+def test_sizes_beyond_the_limits_are_refused_before_anything_is_allocated(motor):
+    """Counts whose padded forms would leave 32 bits are argument errors, not allocation attempts."""
+    import ctypes as C
+    lib = _lib.load()
+    motor.cargar_productos(np.array([100, 200], np.int64))
+    one32 = (C.c_int32 * 4)(5, 0, 1, 0)
+    out = (C.c_int64 * 4)()
+    ctx = motor._ctx
+    rc = lib.acmpc_aggregate(ctx, one32, one32, one32, 1, one32, 1, 5, (1 << 30) + 1, out, out, out)
+    assert rc == _lib.E_INVALID and "customers" in lib.acmpc_last_error(ctx).decode()
+    rc = lib.acmpc_aggregate(ctx, one32, one32, one32, 1, one32, 1 << 31, 5, 1, out, out, out)
+    assert rc == _lib.E_INVALID
+    price = (C.c_int64 * 1)(1)
+    assert lib.acmpc_set_products(ctx, price, (1 << 28) + 1) == _lib.E_INVALID
+    assert lib.acmpc_set_product_codes(ctx, C.create_string_buffer(32), (1 << 24) + 1) == _lib.E_INVALID
+    tot, pq, ct = motor.agregar([5, 6], [0, 1], [1, 1], [0, 0], 5, 1)      # the context still works
+    assert tot.tolist() == [100, 200] and pq.tolist() == [1, 1] and ct.tolist() == [300]
+
+
 # ---- device-resident path, generator parity, properties at full size ------------------------------
 
 def _device_run(motor, ds):
