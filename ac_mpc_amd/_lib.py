@@ -19,6 +19,7 @@ EXPORTS = (
     "acmpc_synth_generate_device", "acmpc_set_product_codes", "acmpc_ingest_detalle_device", "acmpc_ingest_detalle",
     "acmpc_aggregate_lifecycle", "acmpc_aggregate_lifecycle_device",
     "acmpc_emit_totals_device", "acmpc_emit_stock_device", "acmpc_emit_totals", "acmpc_emit_stock",
+    "acmpc_host_alloc", "acmpc_host_free",
 )
 
 OK, E_INVALID, E_HIP, E_ALIGN, E_DATA, E_STATE, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
@@ -109,6 +110,10 @@ def load() -> C.CDLL:
     lib.acmpc_synth_prices.restype = C.c_int
     lib.acmpc_synth_generate_device.argtypes = [vp, C.POINTER(SynthCfg), vp, vp, vp, vp, vp]
     lib.acmpc_synth_generate_device.restype = C.c_int
+    lib.acmpc_host_alloc.argtypes = [vp, i64, C.POINTER(vp)]
+    lib.acmpc_host_alloc.restype = C.c_int
+    lib.acmpc_host_free.argtypes = [vp, vp]
+    lib.acmpc_host_free.restype = C.c_int
     lib.acmpc_set_product_codes.argtypes = [vp, vp, i32]
     lib.acmpc_set_product_codes.restype = C.c_int
     lib.acmpc_ingest_detalle_device.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp, vp]

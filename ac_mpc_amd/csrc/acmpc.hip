@@ -100,6 +100,9 @@ struct acmpc_ctx {
   int force_global_tables = 0;
   int line_order = ACMPC_ORDER_GROUPED;
 
+  // page-locked host buffers handed out by acmpc_host_alloc
+  std::vector<void*> host_blocks;
+
   // profiling
   bool profiling = false;
   hipEvent_t ev[ACMPC_N_KERNELS + 1] = {};
@@ -144,6 +147,19 @@ struct DeviceScope {
 #define ENTER_DEVICE(ctx)   \
   DeviceScope device_scope_; \
   HIPCHK(ctx, device_scope_.enter((ctx)->device))
+
+// Entry points whose host side uses standard containers run inside this guard: no exception may
+// cross the C boundary, and running out of host memory is an error code like any other.
+template <typename F>
+int guarded(acmpc_ctx* ctx, const char* who, F&& body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return fail(ctx, ACMPC_E_NOMEM, "%s: out of host memory", who);
+  } catch (...) {
+    return fail(ctx, ACMPC_E_INVALID, "%s: unexpected exception", who);
+  }
+}
 
 template <typename T>
 int ensure(acmpc_ctx* ctx, DevBuf<T>& b, size_t n, bool zero_new = false) {
@@ -648,6 +664,8 @@ ACMPC_API void acmpc_destroy(acmpc_ctx* ctx) {
   release(ctx->d_dict); release(ctx->d_dict_disp); release(ctx->d_codes); release(ctx->d_chunk_rows); release(ctx->d_ing_tables);
   release(ctx->s_text); release(ctx->d_chunk_bytes); release(ctx->s_emit_value);
   release(ctx->s_line_price); release(ctx->s_order_state); release(ctx->s_order_descuento);
+  for (void* p : ctx->host_blocks) (void)hipHostFree(p);
+  ctx->host_blocks.clear();
   if (ctx->d_ing_scalars) (void)hipFree(ctx->d_ing_scalars);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   for (int i = 0; i <= ACMPC_N_KERNELS; ++i)
@@ -827,6 +845,32 @@ ACMPC_API int acmpc_lines_geometry(acmpc_ctx* ctx, int32_t* n_workgroups, int32_
   return ACMPC_OK;
 }
 
+ACMPC_API int acmpc_host_alloc(acmpc_ctx* ctx, int64_t n_bytes, void** out) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_host_alloc: null context");
+  if (!out) return fail(ctx, ACMPC_E_INVALID, "acmpc_host_alloc: null out pointer");
+  *out = nullptr;
+  if (n_bytes < 0) return fail(ctx, ACMPC_E_INVALID, "acmpc_host_alloc: negative size");
+  ENTER_DEVICE(ctx);
+  void* p = nullptr;
+  HIPCHK(ctx, hipHostMalloc(&p, (size_t)std::max<int64_t>(n_bytes, 16), hipHostMallocDefault));
+  const int rc = guarded(ctx, "acmpc_host_alloc", [&] { ctx->host_blocks.push_back(p); return (int)ACMPC_OK; });
+  if (rc) { (void)hipHostFree(p); return rc; }
+  *out = p;
+  return ACMPC_OK;
+}
+
+ACMPC_API int acmpc_host_free(acmpc_ctx* ctx, void* p) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_host_free: null context");
+  if (!p) return ACMPC_OK;
+  auto it = std::find(ctx->host_blocks.begin(), ctx->host_blocks.end(), p);
+  if (it == ctx->host_blocks.end())
+    return fail(ctx, ACMPC_E_INVALID, "acmpc_host_free: not a block of this context");
+  ENTER_DEVICE(ctx);
+  ctx->host_blocks.erase(it);
+  HIPCHK(ctx, hipHostFree(p));          // waits for copies that still use the block
+  return ACMPC_OK;
+}
+
 // ---- synthetic data ----------------------------------------------------------------------
 
 ACMPC_API int acmpc_synth_plan(const acmpc_synth_cfg* cfg, acmpc_synth_shard* out) {
@@ -851,10 +895,23 @@ ACMPC_API int acmpc_synth_prices(const acmpc_synth_cfg* cfg, int64_t* price_cent
   return ACMPC_OK;
 }
 
+namespace {
+int synth_generate_impl(acmpc_ctx* ctx, const acmpc_synth_cfg* cfg, int32_t* d_order_id, int32_t* d_product_idx,
+                        int32_t* d_qty, int32_t* d_order_customer, void* hip_stream);
+}
+
 ACMPC_API int acmpc_synth_generate_device(acmpc_ctx* ctx, const acmpc_synth_cfg* cfg, int32_t* d_order_id,
                                           int32_t* d_product_idx, int32_t* d_qty, int32_t* d_order_customer,
                                           void* hip_stream) {
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_synth_generate_device: null context");
+  return guarded(ctx, "acmpc_synth_generate_device", [&] {
+    return synth_generate_impl(ctx, cfg, d_order_id, d_product_idx, d_qty, d_order_customer, hip_stream);
+  });
+}
+
+namespace {
+int synth_generate_impl(acmpc_ctx* ctx, const acmpc_synth_cfg* cfg, int32_t* d_order_id, int32_t* d_product_idx,
+                        int32_t* d_qty, int32_t* d_order_customer, void* hip_stream) {
   int rc = synth_check(ctx, cfg);
   if (rc) return rc;
   ENTER_DEVICE(ctx);
@@ -892,11 +949,21 @@ ACMPC_API int acmpc_synth_generate_device(acmpc_ctx* ctx, const acmpc_synth_cfg*
   HIPCHK(ctx, hipGetLastError());
   return ACMPC_OK;
 }
+}  // namespace
 
 // ---- text ingest -------------------------------------------------------------------------
 
+namespace {
+int set_product_codes_impl(acmpc_ctx* ctx, const char* codes32, int32_t n_products);
+}
+
 ACMPC_API int acmpc_set_product_codes(acmpc_ctx* ctx, const char* codes32, int32_t n_products) {
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_set_product_codes: null context");
+  return guarded(ctx, "acmpc_set_product_codes", [&] { return set_product_codes_impl(ctx, codes32, n_products); });
+}
+
+namespace {
+int set_product_codes_impl(acmpc_ctx* ctx, const char* codes32, int32_t n_products) {
   if (!codes32 || n_products <= 0) return fail(ctx, ACMPC_E_INVALID, "acmpc_set_product_codes: empty code list");
   if (n_products > kMaxCodes) return fail(ctx, ACMPC_E_INVALID, "acmpc_set_product_codes: more than %d codes", kMaxCodes);
   ENTER_DEVICE(ctx);
@@ -1011,6 +1078,7 @@ ACMPC_API int acmpc_set_product_codes(acmpc_ctx* ctx, const char* codes32, int32
   ctx->code_csv_bad = csv_bad;
   return ACMPC_OK;
 }
+}  // namespace
 
 ACMPC_API int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, int64_t n_bytes, int32_t* d_order_id,
                                           int32_t* d_product_idx, int32_t* d_qty, int64_t capacity_rows,

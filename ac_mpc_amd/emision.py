@@ -21,24 +21,32 @@ SQL, CSV = _lib.EMIT_SQL, _lib.EMIT_CSV
 MAX_FILA_TOTALES, MAX_FILA_STOCK = 83, 103
 
 
-def _host(motor: MotorLote, fn, valores: np.ndarray, extra, estilo: int, max_fila: int) -> bytes:
+def _host(motor: MotorLote, fn, valores: np.ndarray, extra, estilo: int, max_fila: int, salida):
     v = np.ascontiguousarray(valores, np.int64)
-    cap = max(int(v.size) * max_fila, 1)
-    buf = C.create_string_buffer(cap)
+    if salida is not None:
+        if not (isinstance(salida, np.ndarray) and salida.dtype == np.uint8 and salida.ndim == 1
+                and salida.flags.c_contiguous and salida.flags.writeable):
+            raise ErrorLote(_lib.E_INVALID, "la salida debe ser un arreglo uint8 contiguo")
+        buf = salida
+    else:
+        buf = np.empty(max(int(v.size) * max_fila, 1), np.uint8)      # the bound on the rows' sizes: never too small
     n = C.c_int64(0)
-    motor._check(fn(motor._ctx, v.ctypes.data, v.size, *extra, estilo, buf, cap, C.byref(n)))
-    return buf.raw[:int(n.value)]
+    motor._check(fn(motor._ctx, v.ctypes.data, v.size, *extra, estilo, buf.ctypes.data, buf.size, C.byref(n)))
+    return buf[:int(n.value)] if salida is not None else buf[:int(n.value)].tobytes()
 
 
-def totales(motor: MotorLote, total_centavos, base_pedido: int, estilo: int = SQL) -> bytes:
-    """Host totals (int64 cents, one per order) -> the audit rows of venta.TotalPagar, as bytes."""
-    return _host(motor, motor._lib.acmpc_emit_totals, total_centavos, (int(base_pedido),), estilo, MAX_FILA_TOTALES)
+def totales(motor: MotorLote, total_centavos, base_pedido: int, estilo: int = SQL, salida=None):
+    """Host totals (int64 cents, one per order) -> the audit rows of venta.TotalPagar, as bytes.
+    With `salida` (a uint8 numpy array, for instance from `MotorLote.reservar_host`) the text is written
+    there and the filled part of that array is returned; too small an array raises ErrorLote (E_DATA)."""
+    return _host(motor, motor._lib.acmpc_emit_totals, total_centavos, (int(base_pedido),), estilo, MAX_FILA_TOTALES,
+                 salida)
 
 
-def stock(motor: MotorLote, delta_stock, estilo: int = SQL) -> bytes:
+def stock(motor: MotorLote, delta_stock, estilo: int = SQL, salida=None):
     """Host stock deltas (int64, one per product of the loaded code list) -> the rows that decrement
-    producto.Stock; products whose delta is zero get no row."""
-    return _host(motor, motor._lib.acmpc_emit_stock, delta_stock, (), estilo, MAX_FILA_STOCK)
+    producto.Stock; products whose delta is zero get no row.  `salida` as in `totales`."""
+    return _host(motor, motor._lib.acmpc_emit_stock, delta_stock, (), estilo, MAX_FILA_STOCK, salida)
 
 
 def totales_device(motor: MotorLote, total_centavos, base_pedido: int, estilo: int, texto, n_bytes, stream=None) -> None:

@@ -32,16 +32,34 @@ def cargar_codigos(motor: MotorLote, codigos: Sequence[str]) -> None:
     motor._check(motor._lib.acmpc_set_product_codes(motor._ctx, packed.ctypes.data, len(codigos)))
 
 
-def leer_detalle(motor: MotorLote, texto: bytes, capacidad: int = -1) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+def leer_detalle(motor: MotorLote, texto, capacidad: int = -1, salida=None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """Host text in, host columns out: (order_id, product_idx, qty), rows in text order.
+    `texto` is bytes or a one-dimensional uint8 numpy array (for instance one from
+    `MotorLote.reservar_host`, which the GPU reads by direct DMA); `salida` optionally names three int32
+    arrays of equal length (the row capacity) that receive the columns.
     Raises ErrorLote (E_DATA) on a malformed data row."""
-    if capacidad < 0:
-        capacidad = texto.count(b"\n") + 1
-    oid = np.empty(max(capacidad, 1), np.int32)
-    pidx = np.empty(max(capacidad, 1), np.int32)
-    qty = np.empty(max(capacidad, 1), np.int32)
+    if isinstance(texto, np.ndarray):
+        if texto.dtype != np.uint8 or texto.ndim != 1 or not texto.flags.c_contiguous:
+            raise ErrorLote(_lib.E_INVALID, "el texto debe ser bytes o un arreglo uint8 contiguo")
+        ptr, n_bytes = texto.ctypes.data, texto.size
+    else:
+        ptr, n_bytes = texto, len(texto)
+    if salida is not None:
+        oid, pidx, qty = salida
+        for a in salida:
+            if not (isinstance(a, np.ndarray) and a.dtype == np.int32 and a.ndim == 1 and a.size == oid.size
+                    and a.flags.c_contiguous and a.flags.writeable):
+                raise ErrorLote(_lib.E_INVALID, "columnas de salida de tipo o longitud incorrectos")
+        if capacidad < 0 or capacidad > oid.size:
+            capacidad = oid.size
+    else:
+        if capacidad < 0:       # one row per line at most
+            capacidad = 1 + (int(np.count_nonzero(texto == 10)) if isinstance(texto, np.ndarray) else texto.count(b"\n"))
+        oid = np.empty(max(capacidad, 1), np.int32)
+        pidx = np.empty(max(capacidad, 1), np.int32)
+        qty = np.empty(max(capacidad, 1), np.int32)
     n, bad = C.c_int64(0), C.c_int64(0)
-    motor._check(motor._lib.acmpc_ingest_detalle(motor._ctx, texto, len(texto), oid.ctypes.data, pidx.ctypes.data,
+    motor._check(motor._lib.acmpc_ingest_detalle(motor._ctx, ptr, n_bytes, oid.ctypes.data, pidx.ctypes.data,
                                                  qty.ctypes.data, capacidad, C.byref(n), C.byref(bad)))
     k = int(n.value)
     return oid[:k], pidx[:k], qty[:k]

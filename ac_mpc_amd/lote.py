@@ -45,12 +45,14 @@ class MotorLote:
             raise ErrorLote(rc, self._lib.acmpc_last_error(None).decode())
         self.device = int(device)
         self.n_products = 0
+        self._host_blocks: Dict[int, int] = {}     # address of a page-locked array -> its block
 
     # -- lifecycle ------------------------------------------------------------------------
     def cerrar(self) -> None:
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
-            self._lib.acmpc_destroy(self._ctx)
+            self._lib.acmpc_destroy(self._ctx)          # also releases the page-locked blocks
             self._ctx = C.c_void_p()
+            self._host_blocks = {}
 
     close = cerrar
 
@@ -72,9 +74,31 @@ class MotorLote:
         self._check(self._lib.acmpc_set_products(self._ctx, price.ctypes.data, price.size))
         self.n_products = int(price.size)
 
+    # -- page-locked host memory ---------------------------------------------------------------
+    def reservar_host(self, n: int, dtype) -> np.ndarray:
+        """A numpy array of `n` elements in page-locked memory owned by this context: columns filled in
+        place there (and results received there, see `agregar(salida=...)`) cross to the GPU by direct
+        DMA.  The array is valid until `liberar_host(array)` or `cerrar()`; using it afterwards is a
+        use-after-free, as with any buffer of a C library."""
+        dt = np.dtype(dtype)
+        nbytes = max(1, int(n) * dt.itemsize)
+        p = C.c_void_p()
+        self._check(self._lib.acmpc_host_alloc(self._ctx, nbytes, C.byref(p)))
+        arr = np.frombuffer((C.c_char * nbytes).from_address(p.value), dtype=dt, count=int(n))
+        self._host_blocks[p.value] = p.value
+        return arr
+
+    def liberar_host(self, arr: np.ndarray) -> None:
+        addr = arr.ctypes.data if arr.size else None
+        block = self._host_blocks.pop(addr, None) if addr is not None else None
+        if block is None:
+            raise ErrorLote(_lib.E_INVALID, "el arreglo no viene de reservar_host (o esta vacio)")
+        self._check(self._lib.acmpc_host_free(self._ctx, block))
+
     # -- host columns in, host results out ----------------------------------------------------
     def agregar(self, order_id, product_idx, qty, order_customer, order_id_base: int, n_customers: int,
-                precio_linea=None, estado_pedido=None, descuento=None, descuento_porcentaje: bool = False
+                precio_linea=None, estado_pedido=None, descuento=None, descuento_porcentaje: bool = False,
+                salida: Optional[Tuple[np.ndarray, np.ndarray, np.ndarray]] = None
                 ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """Return (order_total_cents[M], product_qty[P], customer_total_cents[C]).
 
@@ -87,6 +111,9 @@ class MotorLote:
         order counts (cleared for an Estado that means cancelled, process/updatePedido.php:11, or a
         deleted order, process/delPedido.php:12-13); `descuento[M]` int32, venta.Descuento (store.sql:162)
         in whole currency units, or per cent with `descuento_porcentaje`.
+
+        `salida`: three int64 arrays (M, P, C) to receive the results instead of new ones, for instance
+        arrays from `reservar_host`.
         """
         oid, pidx, q = _np(order_id, np.int32), _np(product_idx, np.int32), _np(qty, np.int32)
         cust = _np(order_customer, np.int32)
@@ -95,9 +122,16 @@ class MotorLote:
         if self.n_products <= 0:
             raise ErrorLote(_lib.E_STATE, "no se han cargado productos")
         n, m = oid.size, cust.size
-        tot = np.empty(m, dtype=np.int64)
-        pq = np.empty(self.n_products, dtype=np.int64)
-        ct = np.empty(int(n_customers), dtype=np.int64)
+        if salida is not None:
+            tot, pq, ct = salida
+            for arr, size in ((tot, m), (pq, self.n_products), (ct, int(n_customers))):
+                if not (isinstance(arr, np.ndarray) and arr.dtype == np.int64 and arr.ndim == 1 and arr.size == size
+                        and arr.flags.c_contiguous and arr.flags.writeable):
+                    raise ErrorLote(_lib.E_INVALID, "arreglo de salida de tipo o longitud incorrectos")
+        else:
+            tot = np.empty(m, dtype=np.int64)
+            pq = np.empty(self.n_products, dtype=np.int64)
+            ct = np.empty(int(n_customers), dtype=np.int64)
         keep = []
         life = None
         if precio_linea is not None or estado_pedido is not None or descuento is not None:

@@ -51,6 +51,8 @@ class consultasLote {
                             int32_t order_id_base, int style, char* text, int64_t capacity_bytes, int64_t* n_bytes);
         int acmpc_emit_stock(acmpc_ctx* ctx, const int64_t* product_qty, int32_t n_products, int style,
                             char* text, int64_t capacity_bytes, int64_t* n_bytes);
+        int acmpc_host_alloc(acmpc_ctx* ctx, int64_t n_bytes, void** out);
+        int acmpc_host_free(acmpc_ctx* ctx, void* p);
     ";
 
     /* Counterpart of ejecutarSQL::conectar() (library/consulSQL.php:5-16). */
@@ -73,6 +75,24 @@ class consultasLote {
         $col = self::$ffi->new($tipo . "[" . max($n, 1) . "]");
         for ($i = 0; $i < $n; $i++) $col[$i] = $valores[$i];
         return $col;
+    }
+
+    /*
+     * A column of $n elements of $tipo ("int32_t", "int64_t") in page-locked memory of the context: a
+     * worker that fills such columns in place (instead of PHP arrays, as $_SESSION['carro'] is at
+     * process/carrito.php:8-10) and passes them to acmpc_aggregate gets its copies at the PCIe rate.
+     * Index it like an FFI array; release it with LiberarColumna.
+     */
+    public static function ReservarColumna($tipo, $n) {
+        self::conectar();
+        $p = self::$ffi->new("void*");
+        self::comprobar(self::$ffi->acmpc_host_alloc(self::$ctx, max($n, 1) * FFI::sizeof(self::$ffi->type($tipo)),
+                                                     FFI::addr($p)), "reservar memoria");
+        return self::$ffi->cast($tipo . "*", $p);
+    }
+
+    public static function LiberarColumna($col) {
+        self::comprobar(self::$ffi->acmpc_host_free(self::$ctx, self::$ffi->cast("void*", $col)), "liberar memoria");
     }
 
     /* producto.Precio in integer cents, in dictionary order (store.sql:110,113). */

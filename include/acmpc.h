@@ -236,6 +236,20 @@ int acmpc_last_kernel_ms(acmpc_ctx* ctx, float* ms);
 /* Launch geometry of the order-line pass: workgroups and waves per workgroup. */
 int acmpc_lines_geometry(acmpc_ctx* ctx, int32_t* n_workgroups, int32_t* waves_per_workgroup);
 
+/*
+ * Page-locked host memory for the columns, texts and results handed to the
+ * host-pointer entry points (acmpc_aggregate, acmpc_ingest_detalle, acmpc_emit_*).
+ * Those calls accept any host pointer; from a buffer obtained here the copies to
+ * and from the GPU run as direct DMA at the link's rate, from ordinary memory the
+ * runtime stages them through its own buffers at a fraction of it.
+ * *out is 16-byte aligned, belongs to the context and is released by
+ * acmpc_host_free() or, at the latest, by acmpc_destroy().
+ * Replaces the PHP arrays in which the reference holds a cart
+ * ($_SESSION['carro'], process/carrito.php:8-10; process/confirmcompra.php:35).
+ */
+int acmpc_host_alloc(acmpc_ctx* ctx, int64_t n_bytes, void** out);
+int acmpc_host_free(acmpc_ctx* ctx, void* p);
+
 /* ------------------------------------------------------------------------
  * Text ingest: `detalle` rows as SQL-dump / CSV text -> the three int32 columns.
  *

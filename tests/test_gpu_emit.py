@@ -82,6 +82,23 @@ def test_capacity_too_small_is_reported(motor, oracle):
     assert motor.estado() == 0                                        # the flag was consumed by the call
 
 
+def test_text_into_a_page_locked_array(motor, oracle, em):
+    from ac_mpc_amd import ErrorLote, _lib
+    vals = motor.reservar_host(5000, np.int64)
+    vals[:] = ec.random_values(5000, 9)
+    out = motor.reservar_host(5000 * em.MAX_FILA_TOTALES, np.uint8)
+    got = em.totales(motor, vals, 5, em.SQL, salida=out)
+    assert got.ctypes.data == out.ctypes.data and got.tobytes() == oracle.emit_totals(vals, 5, 0)
+    small = motor.reservar_host(100, np.uint8)
+    with pytest.raises(ErrorLote) as e:
+        em.totales(motor, vals, 5, em.SQL, salida=small)
+    assert e.value.code == _lib.E_DATA
+    with pytest.raises(ErrorLote):
+        em.totales(motor, vals, 5, em.SQL, salida=np.zeros(10, np.int32))
+    for a in (vals, out, small):
+        motor.liberar_host(a)
+
+
 @pytest.mark.parametrize("style", [0, 1])
 def test_device_totals_at_bench_size_properties(motor, oracle, em, style):
     """25 M orders (config-3 order count): size, row count and windows of the text against the oracle."""

@@ -199,3 +199,26 @@ def test_ingest_then_aggregate_equals_oracle(motor, oracle):
     np.testing.assert_array_equal(tot.cpu().numpy(), etot)
     np.testing.assert_array_equal(pq.cpu().numpy(), epq)
     np.testing.assert_array_equal(ct.cpu().numpy(), ect)
+
+
+def test_page_locked_text_and_columns(motor, oracle):
+    """Text held in a page-locked uint8 array and columns received in page-locked arrays: same rows."""
+    codes = [ic.code_of(p) for p in range(50)]
+    rng = np.random.default_rng(5)
+    n = 20_000
+    oid = np.sort(rng.integers(5, 4000, n)).tolist()
+    text = ic.render(oid, rng.integers(0, 50, n).tolist(), rng.integers(1, 9, n).tolist(), "dump")
+    ingesta.cargar_codigos(motor, codes)
+    locked = motor.reservar_host(len(text), np.uint8)
+    locked[:] = np.frombuffer(text, np.uint8)
+    cols = tuple(motor.reservar_host(n + 3, np.int32) for _ in range(3))
+    got = ingesta.leer_detalle(motor, locked, salida=cols)
+    eoid, epidx, eqty, rows, bad = oracle.ingest(text, codes)
+    assert rows == n and bad == 0 and got[0].size == n
+    for g, e, c in zip(got, (eoid, epidx, eqty), cols):
+        np.testing.assert_array_equal(g, e)
+        assert g.ctypes.data == c.ctypes.data          # views of the caller's arrays, not copies
+    with pytest.raises(ErrorLote):
+        ingesta.leer_detalle(motor, locked.astype(np.int32))
+    for a in (locked,) + cols:
+        motor.liberar_host(a)

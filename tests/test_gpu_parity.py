@@ -243,6 +243,42 @@ def test_sizes_beyond_the_limits_are_refused_before_anything_is_allocated(motor)
     assert tot.tolist() == [100, 200] and pq.tolist() == [1, 1] and ct.tolist() == [300]
 
 
+def test_page_locked_columns_and_results(motor, oracle):
+    """Columns filled in place in page-locked arrays, results received in page-locked arrays: same sums."""
+    rng = np.random.default_rng(77)
+    m, c, p = 3000, 40, 25
+    lens = rng.integers(0, 6, m)
+    n = int(lens.sum())
+    price = rng.integers(1, 90000, p).astype(np.int64)
+    motor.cargar_productos(price)
+    oid = motor.reservar_host(n, np.int32)
+    pidx = motor.reservar_host(n, np.int32)
+    qty = motor.reservar_host(n, np.int32)
+    cust = motor.reservar_host(m, np.int32)
+    out = (motor.reservar_host(m, np.int64), motor.reservar_host(p, np.int64), motor.reservar_host(c, np.int64))
+    assert all(a.ctypes.data % 16 == 0 for a in (oid, pidx, qty, cust) + out)
+    oid[:] = np.repeat(np.arange(m, dtype=np.int32) + 5, lens)
+    pidx[:] = rng.integers(-1, p + 1, n)
+    qty[:] = rng.integers(0, 4, n)
+    cust[:] = rng.integers(0, c, m)
+    tot, pq, ct = motor.agregar(oid, pidx, qty, cust, 5, c, salida=out)
+    assert tot is out[0] and pq is out[1] and ct is out[2]
+    etot, epq, ect, flags = oracle.aggregate(oid, pidx, qty, cust, 5, c, price)
+    assert flags == 0
+    np.testing.assert_array_equal(tot, etot)
+    np.testing.assert_array_equal(pq, epq)
+    np.testing.assert_array_equal(ct, ect)
+    motor.liberar_host(oid)
+    with pytest.raises(ErrorLote):
+        motor.liberar_host(oid)                         # already released
+    with pytest.raises(ErrorLote):
+        motor.liberar_host(np.zeros(4, np.int32))       # not a block of the context
+    with pytest.raises(ErrorLote):
+        motor.agregar(pidx, pidx, qty, cust, 5, c, salida=(out[0][:-1], out[1], out[2]))
+    empty = motor.reservar_host(0, np.int64)            # a zero-length request is still a valid block
+    assert empty.size == 0
+
+
 # ---- device-resident path, generator parity, properties at full size ------------------------------
 
 def _device_run(motor, ds):

@@ -20,9 +20,27 @@ for _ in range(2):
     dt = time.perf_counter() - t0
 assert oid.size == n_rows
 print(f"ingest, host pointers: {n_rows} rows, {len(text)/1e9:.2f} GB text in {dt*1e3:.1f} ms = {n_rows/dt/1e9:.2f} G rows/s, {len(text)/dt/1e9:.1f} GB/s of text (PCIe included)")
+ltext = m.reservar_host(len(text), np.uint8)
+ltext[:] = np.frombuffer(text, np.uint8)
+lcols = tuple(m.reservar_host(n_rows, np.int32) for _ in range(3))
+for _ in range(2):
+    t0 = time.perf_counter()
+    oid2, pidx2, qty2 = ingesta.leer_detalle(m, ltext, n_rows, salida=lcols)
+    dt = time.perf_counter() - t0
+assert np.array_equal(oid2, oid) and np.array_equal(pidx2, pidx) and np.array_equal(qty2, qty)
+print(f"ingest, page-locked text and columns: {n_rows} rows in {dt*1e3:.1f} ms = {n_rows/dt/1e9:.2f} G rows/s, {len(text)/dt/1e9:.1f} GB/s of text (PCIe included)")
 tot = np.random.default_rng(1).integers(100, 3_500_000, size=5_000_000, dtype=np.int64)
 for _ in range(2):
     t0 = time.perf_counter()
     out = emision.totales(m, tot, 5)
     dt = time.perf_counter() - t0
 print(f"emit, host pointers: {tot.size} rows -> {len(out)/1e9:.2f} GB text in {dt*1e3:.1f} ms = {tot.size/dt/1e9:.2f} G rows/s, {len(out)/dt/1e9:.1f} GB/s of text (PCIe included)")
+ltot = m.reservar_host(tot.size, np.int64)
+ltot[:] = tot
+lout = m.reservar_host(tot.size * emision.MAX_FILA_TOTALES, np.uint8)
+for _ in range(2):
+    t0 = time.perf_counter()
+    out2 = emision.totales(m, ltot, 5, salida=lout)
+    dt = time.perf_counter() - t0
+assert out2.tobytes() == out
+print(f"emit, page-locked totals and text: {tot.size} rows in {dt*1e3:.1f} ms = {tot.size/dt/1e9:.2f} G rows/s, {len(out)/dt/1e9:.1f} GB/s of text (PCIe included)")
