@@ -1116,7 +1116,7 @@ ACMPC_API int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, in
   }
   // entries and ticket start at zero; chunks are handed out in order, so any grid size is safe
   HIPCHK(ctx, hipMemsetAsync(ctx->d_chunk_rows.p, 0, ((size_t)a.n_chunks + 1) * 8, st));
-  const int blocks = (int)std::min<int64_t>(a.n_chunks, (int64_t)ctx->n_cu * 4);
+  const int blocks = (int)std::min<int64_t>(a.n_chunks, (int64_t)ctx->n_cu * kIngBlocksPerCu);
   hipLaunchKernelGGL(k_ingest_parse, dim3(blocks), dim3(kIngThreads), 0, st, a);
   HIPCHK(ctx, hipGetLastError());
   return ACMPC_OK;

@@ -7,19 +7,22 @@
 // separated rows.  The grammar is spelled out in include/acmpc.h.
 //
 // One pass over the text (byte work; no MFMA):
-//   k_ingest_parse   16 KiB chunks are handed out in order; every chunk is staged in LDS (plus 128 bytes of lookahead); each thread finds
-//                    the row starts in its 64 bytes and ranks them with a block scan; the rows are
+//   k_ingest_parse   12 KiB chunks are handed out in order; every chunk is staged in LDS (plus 128 bytes of lookahead); each thread finds
+//                    the row starts in its 48 bytes and ranks them with a block scan; the rows are
 //                    then handed out one per thread, run through a table-driven automaton, converted,
 //                    looked up in a hash dictionary of the product codes and written as columns
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace acmpc {
 
 constexpr int kIngThreads = 256;
-constexpr int kIngPerThread = 64;                       // bytes of text per thread
-constexpr int kIngChunk = kIngThreads * kIngPerThread;  // 16 KiB per workgroup iteration
+constexpr int kIngPerThread = 48;                       // bytes of text per thread (a multiple of 16)
+constexpr int kIngChunk = kIngThreads * kIngPerThread;  // 12 KiB per workgroup iteration
+constexpr int kIngWords = kIngPerThread / 4;
+constexpr int kIngBlocksPerCu = 5;                      // resident workgroups per CU (LDS and registers allow five)
 constexpr int kIngLook = 128;                           // lookahead kept in LDS; longest row is 120 bytes
 constexpr int kIngMaxRow = 120;
 constexpr uint32_t kStIngestMalformed = 8u, kStIngestCapacity = 16u;
@@ -62,11 +65,11 @@ __device__ __forceinline__ uint32_t ing_newlines(uint32_t w) {
 
 // Bit k set: a line starts at byte k of the thread's 64 bytes (byte k-1 is '\n', or the text starts
 // there).  Lines are not classified here.
-__device__ __forceinline__ unsigned long long ing_line_start_mask(const uint32_t (&w)[16], uint32_t prev) {
+__device__ __forceinline__ unsigned long long ing_line_start_mask(const uint32_t (&w)[kIngWords], uint32_t prev) {
   unsigned long long mask = 0;
   uint32_t carry = prev == '\n' ? 0x80u : 0u;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < kIngWords; ++j) {
     const uint32_t nl = ing_newlines(w[j]);
     const uint32_t st = (nl << 8) | carry;
     carry = nl >> 24;
@@ -409,12 +412,13 @@ __device__ __forceinline__ bool ing_finish_row(const unsigned char* s_text, int 
   return ok;
 }
 
-__global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) k_ingest_parse(IngestArgs a) {
+__global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_eu(kIngBlocksPerCu, kIngBlocksPerCu))) k_ingest_parse(IngestArgs a) {
   // [16 bytes of slack][chunk][look-ahead][slack]: number and code windows may reach a few bytes outside a row
   __shared__ __align__(16) unsigned char s_text[kIngFront + kIngChunk + kIngLook + 64];
   // start offsets of the chunk's data rows, in text order (a data row takes at least two bytes)
   __shared__ __align__(16) unsigned short s_row[kIngChunk / 2];
-  static_assert(kIngChunk / 2 * 2 >= 1024 * 2 + 3 * 1024 * 4, "parsed columns are parked behind the row list");
+  constexpr int kKeep = 768;                               // parsed rows a chunk can park in LDS
+  static_assert(kIngChunk / 2 * 2 >= kKeep * 2 + 3 * kKeep * 4, "parsed columns are parked behind the row list");
   __shared__ __align__(8) uint2 s_T[kIngTableWords];
   __shared__ unsigned char s_ct[256];
   __shared__ int s_w[kIngThreads / 64];
@@ -452,9 +456,9 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
     const int o = tid * kIngPerThread;
     unsigned long long dmask = 0;
     if (base < a.n_bytes) {
-      uint32_t w[16];
+      uint32_t w[kIngWords];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < kIngWords / 4; ++j) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (o + 16 * j + 16 <= want) v = *reinterpret_cast<const uint4*>(s_chunk + o + 16 * j);
         else {
@@ -467,7 +471,7 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
       const uint32_t prev = base == 0 ? (uint32_t)'\n' : (tid == 0 ? (uint32_t)a.text[base - 1] : (uint32_t)s_chunk[o - 1]);
       unsigned long long smask = ing_line_start_mask(w, prev);
       const int64_t left = a.n_bytes - base;                 // bytes of text from this thread's first byte on
-      if (left < 64) smask &= (1ull << left) - 1ull;
+      if (left < kIngPerThread) smask &= (1ull << left) - 1ull;
       for (unsigned long long m = smask; m; m &= m - 1ull) {
         const int k = __ffsll((long long)m) - 1;
         const uint32_t c0 = s_chunk[o + k];
@@ -507,23 +511,24 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
       }
       __syncthreads();
     };
-    constexpr int kKeep = 1024;                              // parsed rows a chunk can park in LDS
     if (n_r <= kKeep) {
       // the row list needs n_r entries only; the rest of its space holds the parsed columns meanwhile
       int32_t* s_res = reinterpret_cast<int32_t*>(s_row + kKeep);
-      constexpr int kTogether = 1;                           // rows a thread steps through the automaton at once (2: no gain)
-      for (r = tid; r < n_r; r += kTogether * kIngThreads) {
+      // A thread steps two rows through the automaton at once while more than one batch of rows is left
+      // (the table look-ups of a row depend on each other; a second row fills the waits), one otherwise.
+      auto parse_batch = [&](auto together, int r0) {
+        constexpr int kTogether = decltype(together)::value;
         int p[kTogether];
         uint32_t st16[kTogether], A[kTogether], B[kTogether];
 #pragma unroll
-        for (int q = 0; q < kTogether; ++q) {                // a missing second row repeats the first
-          const int rq = r + q * kIngThreads;
-          p[q] = kIngFront + (int)s_row[rq < n_r ? rq : r];
+        for (int q = 0; q < kTogether; ++q) {                // a missing row repeats the thread's first
+          const int rq = r0 + q * kIngThreads;
+          p[q] = kIngFront + (int)s_row[rq < n_r ? rq : r0];
         }
         ing_scan_rows<kTogether>(s_text, s_ct, s_T, p, st16, A, B);
 #pragma unroll
         for (int q = 0; q < kTogether; ++q) {
-          const int rq = r + q * kIngThreads;
+          const int rq = r0 + q * kIngThreads;
           if (rq < n_r) {
             int32_t oid = 0, pidx = -1, qty = 0;
             // the cheaper conversion when no row of the wave has a long number or a long code
@@ -538,7 +543,11 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
             s_res[rq] = oid; s_res[kKeep + rq] = pidx; s_res[2 * kKeep + rq] = qty;
           }
         }
-      }
+      };
+      int b0 = 0;                                            // first row of the batch (uniform)
+      for (; n_r - b0 > kIngThreads; b0 += 2 * kIngThreads)
+        if (b0 + tid < n_r) parse_batch(std::integral_constant<int, 2>{}, b0 + tid);
+      if (b0 + tid < n_r) parse_batch(std::integral_constant<int, 1>{}, b0 + tid);
       resolve_base();
       const long long rbase = s_base;
       for (r = tid; r < n_r; r += kIngThreads) {               // every thread reads back its own rows
