@@ -348,9 +348,9 @@ __device__ __forceinline__ void ing_scan_rows(const unsigned char* s_text, const
                                               const int (&p)[N], uint32_t (&st16)[N], uint32_t (&A)[N], uint32_t (&B)[N]) {
 #pragma unroll
   for (int q = 0; q < N; ++q) { st16[q] = sStart * kNumClasses; A[q] = 0; B[q] = 0; }
-  for (int j0 = 0; j0 < kIngSteps; j0 += 8) {
+  for (int j0 = 0; j0 < kIngSteps; j0 += 4) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
       for (int q = 0; q < N; ++q) {
         const uint32_t cls = s_ct[s_text[p[q] + j0 + j]];
@@ -450,25 +450,23 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
       }
     }
     if (tid == 0) s_chunk[want] = (unsigned char)'\n';     // sentinel: every row ends in a newline
+    // the 16 bytes in front of the chunk come along (the first thread needs the byte before its slice)
+    if (tid == kIngThreads - 1 && c > 0) *reinterpret_cast<uint4*>(s_text) = *reinterpret_cast<const uint4*>(a.text + cbase - kIngFront);
     __syncthreads();
     const int64_t base = cbase + (int64_t)tid * kIngPerThread;
-    // line starts in this thread's 64 bytes, then the data rows among them (first one or two bytes)
+    // line starts in this thread's slice, then the data rows among them (first one or two bytes)
     const int o = tid * kIngPerThread;
     unsigned long long dmask = 0;
     if (base < a.n_bytes) {
       uint32_t w[kIngWords];
 #pragma unroll
       for (int j = 0; j < kIngWords / 4; ++j) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (o + 16 * j + 16 <= want) v = *reinterpret_cast<const uint4*>(s_chunk + o + 16 * j);
-        else {
-          uint32_t t4[4] = {0, 0, 0, 0};
-          for (int b = 0; b < 16; ++b) if (o + 16 * j + b < want) t4[b >> 2] |= (uint32_t)s_chunk[o + 16 * j + b] << (8 * (b & 3));
-          v = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-        }
+        // whole 16-byte pieces even at the end of the text: what lies past the last byte (the sentinel,
+        // leftovers of an earlier chunk) only sets mask bits that are cleared below
+        const uint4 v = *reinterpret_cast<const uint4*>(s_chunk + o + 16 * j);
         w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
       }
-      const uint32_t prev = base == 0 ? (uint32_t)'\n' : (tid == 0 ? (uint32_t)a.text[base - 1] : (uint32_t)s_chunk[o - 1]);
+      const uint32_t prev = base == 0 ? (uint32_t)'\n' : (uint32_t)s_chunk[o - 1];
       unsigned long long smask = ing_line_start_mask(w, prev);
       const int64_t left = a.n_bytes - base;                 // bytes of text from this thread's first byte on
       if (left < kIngPerThread) smask &= (1ull << left) - 1ull;
