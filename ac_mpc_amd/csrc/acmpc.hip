@@ -1010,6 +1010,7 @@ int set_product_codes_impl(acmpc_ctx* ctx, const char* codes32, int32_t n_produc
   IngSlot empty_slot;
   memset(&empty_slot, 0, sizeof(empty_slot));
   empty_slot.idx = -1;
+  empty_slot.short_idx = -1;
   std::vector<IngSlot> dict;
   std::vector<unsigned short> disp;
   uint32_t seed = 0;
@@ -1049,8 +1050,13 @@ int set_product_codes_impl(acmpc_ctx* ctx, const char* codes32, int32_t n_produc
       if (d == 65536) { built = false; break; }
       disp[by_size[bi]] = (unsigned short)d;
       for (size_t k = 0; k < m.size(); ++k) {
-        dict[slots[k]].idx = m[k];
-        memcpy(dict[slots[k]].w, &codes[(size_t)m[k] * 4], 32);
+        IngSlot& slot = dict[slots[k]];
+        uint32_t kw[8];
+        memcpy(kw, &codes[(size_t)m[k] * 4], 32);
+        memcpy(slot.head, kw, 12);
+        memcpy(slot.tail, kw + 3, 20);
+        slot.idx = m[k];
+        slot.short_idx = (kw[3] | kw[4] | kw[5] | kw[6] | kw[7]) == 0u ? m[k] : -1;
       }
     }
     if (built) break;

@@ -22,6 +22,7 @@ constexpr int kIngThreads = 256;
 constexpr int kIngPerThread = 48;                       // bytes of text per thread (a multiple of 16)
 constexpr int kIngChunk = kIngThreads * kIngPerThread;  // 12 KiB per workgroup iteration
 constexpr int kIngWords = kIngPerThread / 4;
+constexpr int kIngPerTicket = 1;                        // consecutive chunks a workgroup takes at once
 constexpr int kIngBlocksPerCu = 5;                      // resident workgroups per CU (LDS and registers allow five)
 constexpr int kIngLook = 128;                           // lookahead kept in LDS; longest row is 120 bytes
 constexpr int kIngMaxRow = 120;
@@ -34,7 +35,7 @@ struct IngestArgs {
   int64_t n_bytes;
   int64_t n_chunks;
   unsigned long long* chunk_state;    // [n_chunks] zero on entry: see ing_row_base
-  unsigned int* ticket;               // zero on entry: next chunk to hand out
+  unsigned int* ticket;               // zero on entry: next group of kIngPerTicket chunks to hand out
   const IngSlot* dict;            // perfect-hash dictionary of the product codes: one slot per probe
   const unsigned short* dict_disp;       // displacement of every bucket
   uint32_t dict_mask, dict_seed, dict_bucket_shift;
@@ -173,12 +174,17 @@ __host__ __device__ __forceinline__ uint32_t ing_slot_of(IngHash h, uint32_t dis
   return (h.a + disp * (h.b | 1u)) & mask;
 }
 
-// One dictionary slot: the code's eight words and the product index (-1 = empty slot), padded to 64
-// bytes so that a lookup (three independent 16-byte loads) stays inside one 64-byte piece of a cache line.
+// One dictionary slot, 64 bytes (one piece of a cache line).  The first 16 bytes decide a lookup of a
+// code of at most 12 bytes on their own: its three words and `short_idx`, which is the product index
+// when the slot's code has no byte past the twelfth and -1 otherwise (a longer code cannot equal a
+// shorter one).  Longer codes compare all eight words and take `idx`.  An empty slot holds the
+// all-zero code and -1 twice.
 struct alignas(64) IngSlot {
-  uint32_t w[8];
+  uint32_t head[3];        // code words 0..2
+  int32_t short_idx;
+  uint32_t tail[5];        // code words 3..7
   int32_t idx;
-  int32_t pad[7];
+  int32_t pad[6];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -404,45 +410,93 @@ __device__ __forceinline__ bool ing_finish_row(const unsigned char* s_text, int 
     const IngHash h = ing_code_hash(cw, a.dict_seed);
     const uint32_t slot = ing_slot_of(h, a.dict_disp[h.a >> a.dict_bucket_shift], a.dict_mask);
     const uint4* sp = reinterpret_cast<const uint4*>(a.dict + slot);
-    const uint4 s0 = sp[0], s1 = sp[1], s2 = sp[2];
-    const uint32_t diff = (s0.x ^ cw[0]) | (s0.y ^ cw[1]) | (s0.z ^ cw[2]) | (s0.w ^ cw[3]) | (s1.x ^ cw[4]) |
-                          (s1.y ^ cw[5]) | (s1.z ^ cw[6]) | (s1.w ^ cw[7]);
-    if (diff == 0u) pidx = (int32_t)s2.x;               // an empty slot holds the all-zero code and index -1
+    if (NC <= 3) {
+      const uint4 s0 = sp[0];
+      if (((s0.x ^ cw[0]) | (s0.y ^ cw[1]) | (s0.z ^ cw[2])) == 0u) pidx = (int32_t)s0.w;
+    } else {
+      const uint4 s0 = sp[0], s1 = sp[1], s2 = sp[2];
+      const uint32_t diff = (s0.x ^ cw[0]) | (s0.y ^ cw[1]) | (s0.z ^ cw[2]) | (s1.x ^ cw[3]) | (s1.y ^ cw[4]) |
+                            (s1.z ^ cw[5]) | (s1.w ^ cw[6]) | (s2.x ^ cw[7]);
+      if (diff == 0u) pidx = (int32_t)s2.y;
+    }
   }
   return ok;
 }
 
-__global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_eu(kIngBlocksPerCu, kIngBlocksPerCu))) k_ingest_parse(IngestArgs a) {
+__global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_eu(kIngBlocksPerCu * kIngThreads / 256, kIngBlocksPerCu * kIngThreads / 256))) k_ingest_parse(IngestArgs a) {
   // [16 bytes of slack][chunk][look-ahead][slack]: number and code windows may reach a few bytes outside a row
   __shared__ __align__(16) unsigned char s_text[kIngFront + kIngChunk + kIngLook + 64];
   // start offsets of the chunk's data rows, in text order (a data row takes at least two bytes)
   __shared__ __align__(16) unsigned short s_row[kIngChunk / 2];
-  constexpr int kKeep = 768;                               // parsed rows a chunk can park in LDS
+  constexpr int kKeep = kIngChunk / 16;                    // parsed rows a chunk can park in LDS
   static_assert(kIngChunk / 2 * 2 >= kKeep * 2 + 3 * kKeep * 4, "parsed columns are parked behind the row list");
   __shared__ __align__(8) uint2 s_T[kIngTableWords];
   __shared__ unsigned char s_ct[256];
   __shared__ int s_w[kIngThreads / 64];
   __shared__ long long s_base;
-  __shared__ unsigned int s_ticket;
+  __shared__ long long s_ticket;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < kIngTableWords; i += kIngThreads) {
     const unsigned long long e = a.tables[i];
     s_T[i] = make_uint2((uint32_t)e, (uint32_t)(e >> 32));
   }
-  s_ct[tid] = reinterpret_cast<const unsigned char*>(a.tables + kIngTableWords)[tid];
+  if (tid < 256) s_ct[tid] = reinterpret_cast<const unsigned char*>(a.tables + kIngTableWords)[tid];
   if (tid < kIngFront) s_text[tid] = 0;
   unsigned char* s_chunk = s_text + kIngFront;
   unsigned long long bad = 0;
-  for (;;) {
-    if (tid == 0) s_ticket = atomicAdd(a.ticket, 1u);      // chunks are handed out in text order
+  unsigned round = 0;                                      // (timing experiments only)
+  int32_t* s_res = reinterpret_cast<int32_t*>(s_row + kKeep);   // parked columns: [oid | pidx | qty], kKeep each
+
+  // The first output row of chunk c (n_r data rows) comes from its predecessors' counts.  One wave looks
+  // back; the last chunk also knows the total.
+  auto resolve_base = [&](long long c, int n_r) {
+    if (wave == 0) {
+      const long long excl = (a.ablate & 64) ? c * 400 : ing_row_base(a.chunk_state, c, n_r, lane, a.status);
+      if (lane == 0) {
+        s_base = excl;
+        if (c == a.n_chunks - 1) {
+          *a.n_rows = excl + n_r;
+          if (excl + n_r > a.capacity) atomicOr(a.status, kStIngestCapacity);
+        }
+      }
+    }
     __syncthreads();
-    const int64_t c = (int64_t)s_ticket;
+  };
+  // Looking back is cheapest when it is done late (the predecessors have had time to publish), so a
+  // chunk's parsed columns are parked in LDS and written out only after the NEXT chunk of this workgroup
+  // has been staged, ranked and published.  (Every thread parks and reads back the same rows.)
+  long long c_parked = -1;
+  int n_parked = 0;
+  auto flush_parked = [&]() {                              // uniform
+    if (c_parked < 0) return;
+    resolve_base(c_parked, n_parked);
+    const long long rbase = s_base;
+    for (int r = tid; r < n_parked; r += kIngThreads) {
+      const long long row = rbase + r;
+      if (row < a.capacity && !(a.ablate & 8)) { a.order_id[row] = s_res[r]; a.product_idx[row] = s_res[kKeep + r]; a.qty[row] = s_res[2 * kKeep + r]; }
+    }
+    c_parked = -1;
+  };
+
+  for (;;) {
+    // A ticket is kIngPerTicket consecutive chunks.  Tickets go out in text order and a workgroup works
+    // through its chunks in order, so a chunk only ever waits for smaller chunks held by workgroups that
+    // are running.  (One counter bumped for every chunk is a single address, which the memory side updates
+    // some 90 million times a second: with 12 KiB chunks that rate is what bounds this kernel.  Two chunks
+    // per ticket lift the bound but lengthen the look-back by more than they gain, and reading two
+    // counters to bump the one that is behind costs three such accesses instead of one.)
+    if (tid == 0) s_ticket = (a.ablate & 128) ? (long long)(blockIdx.x + gridDim.x * round++) : (long long)atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    const int64_t c_first = (int64_t)s_ticket * kIngPerTicket;
+    if (c_first >= a.n_chunks) break;                      // uniform
+    for (int part = 0; part < kIngPerTicket; ++part) {
+    const int64_t c = c_first + part;
     if (c >= a.n_chunks) break;                            // uniform
     const int64_t cbase = c * kIngChunk;
     // stage chunk + lookahead (16-byte pieces; the text buffer is padded by the host side)
     const int64_t avail = a.n_bytes - cbase;
     const int want = (int)(avail < kIngChunk + kIngLook ? avail : kIngChunk + kIngLook);
-    for (int o = tid * 16; o < want; o += kIngThreads * 16) {
+    for (int o = tid * 16; o < want && !((a.ablate & 16) && c >= (int64_t)gridDim.x); o += kIngThreads * 16) {
       if (o + 16 <= want) {
         *reinterpret_cast<uint4*>(s_chunk + o) = *reinterpret_cast<const uint4*>(a.text + cbase + o);
       } else {
@@ -487,31 +541,17 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
     int woff = 0, n_r = 0;
 #pragma unroll
     for (int k = 0; k < kIngThreads / 64; ++k) { if (k < wave) woff += s_w[k]; n_r += s_w[k]; }
+    // publish as early as possible: successors add this count up long before this chunk knows its base
     if (tid == 0 && !(a.ablate & 64)) ing_publish_own(a.chunk_state, c, n_r);
+    // a long row list would run into the parked columns of the chunk before: write those out first
+    if (n_r > kKeep) { flush_parked(); __syncthreads(); }  // (uniform) every thread has read its parked rows back
     // hand the rows out one per thread: every lane of a wave then parses a row of its own, and
     // consecutive lanes write consecutive output rows
     int r = woff + incl - cnt;
     for (unsigned long long m = dmask; m; m &= m - 1ull, ++r) s_row[r] = (unsigned short)(o + __ffsll((long long)m) - 1);
     __syncthreads();
-    // The chunk's first output row comes from its predecessors' counts.  Looking back is cheapest when it
-    // is done late (the predecessors have had time to publish), so the rows are parsed first and parked
-    // in LDS; only a chunk with more rows than fit there looks back before parsing.
-    auto resolve_base = [&]() {
-      if (wave == 0) {
-        const long long excl = (a.ablate & 64) ? c * 600 : ing_row_base(a.chunk_state, c, n_r, lane, a.status);
-        if (lane == 0) {
-          s_base = excl;
-          if (c == a.n_chunks - 1) {                         // the last chunk knows the total
-            *a.n_rows = excl + n_r;
-            if (excl + n_r > a.capacity) atomicOr(a.status, kStIngestCapacity);
-          }
-        }
-      }
-      __syncthreads();
-    };
     if (n_r <= kKeep) {
-      // the row list needs n_r entries only; the rest of its space holds the parsed columns meanwhile
-      int32_t* s_res = reinterpret_cast<int32_t*>(s_row + kKeep);
+      flush_parked();                                      // the chunk before: its look-back comes late, after this publish
       // A thread steps two rows through the automaton at once while more than one batch of rows is left
       // (the table look-ups of a row depend on each other; a second row fills the waits), one otherwise.
       auto parse_batch = [&](auto together, int r0) {
@@ -523,7 +563,12 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
           const int rq = r0 + q * kIngThreads;
           p[q] = kIngFront + (int)s_row[rq < n_r ? rq : r0];
         }
-        ing_scan_rows<kTogether>(s_text, s_ct, s_T, p, st16, A, B);
+        if (a.ablate & 4) {
+#pragma unroll
+          for (int q = 0; q < kTogether; ++q) { st16[q] = sDone * kNumClasses; A[q] = 0x01000000u | (uint32_t)p[q]; B[q] = 0; }
+        } else {
+          ing_scan_rows<kTogether>(s_text, s_ct, s_T, p, st16, A, B);
+        }
 #pragma unroll
         for (int q = 0; q < kTogether; ++q) {
           const int rq = r0 + q * kIngThreads;
@@ -546,14 +591,11 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
       for (; n_r - b0 > kIngThreads; b0 += 2 * kIngThreads)
         if (b0 + tid < n_r) parse_batch(std::integral_constant<int, 2>{}, b0 + tid);
       if (b0 + tid < n_r) parse_batch(std::integral_constant<int, 1>{}, b0 + tid);
-      resolve_base();
-      const long long rbase = s_base;
-      for (r = tid; r < n_r; r += kIngThreads) {               // every thread reads back its own rows
-        const long long row = rbase + r;
-        if (row < a.capacity) { a.order_id[row] = s_res[r]; a.product_idx[row] = s_res[kKeep + r]; a.qty[row] = s_res[2 * kKeep + r]; }
-      }
+      c_parked = c;
+      n_parked = n_r;
     } else {
-      resolve_base();
+      // more rows than can be parked (rows of a few bytes): look back first, write as they are parsed
+      resolve_base(c, n_r);
       const long long rbase = s_base;
       for (r = tid; r < n_r; r += kIngThreads) {
         int32_t oid = 0, pidx = -1, qty = 0;
@@ -566,8 +608,10 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
         if (row < a.capacity) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }
       }
     }
-    __syncthreads();
+    __syncthreads();                                       // the text and the row list are free again
+    }
   }
+  flush_parked();
   if (bad) {
     atomicAdd(a.n_malformed, bad);
     atomicOr(a.status, kStIngestMalformed);

@@ -22,9 +22,13 @@ for style in ("dump", "csv"):
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     for _ in range(2):
         ingesta.leer_detalle_device(m, text, oid, pidx, qty, cnt)
-    m.estado()
-    assert int(cnt.item()) == n_rows or os.environ.get("ACMPC_ING_ABLATE"), (int(cnt.item()), n_rows)
     ablated = bool(int(os.environ.get("ACMPC_ING_ABLATE", "0")))
+    try:
+        m.estado()
+    except Exception:
+        if not ablated:          # with parts of the kernel switched off the flags mean nothing
+            raise
+    assert int(cnt.item()) == n_rows or ablated, (int(cnt.item()), n_rows)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
