@@ -133,7 +133,9 @@ __device__ __forceinline__ long long ing_row_base(unsigned long long* state, lon
     }
     if (__ballot(waiting)) {                             // a predecessor has not published yet
       if (++polls > (1u << 24)) { if (lane == 0) atomicOr(status, kStInternal); break; }   // never expected
-      __builtin_amdgcn_s_sleep(2);
+      // back off: every poll reads lines that the publishers are about to write, and the memory side
+      // serves one address only so often
+      if (polls < 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
       continue;
     }
 #pragma unroll
