@@ -48,6 +48,9 @@ def test_null_context_calls_fail_cleanly():
     assert lib.acmpc_set_profiling(None, 1) == _lib.E_INVALID
     flags = C.c_uint32(0)
     assert lib.acmpc_status(None, None, C.byref(flags)) == _lib.E_INVALID
+    out = C.c_void_p(1)
+    assert lib.acmpc_host_alloc(None, 64, C.byref(out)) == _lib.E_INVALID
+    assert lib.acmpc_host_free(None, None) == _lib.E_INVALID
     lib.acmpc_destroy(None)      # no-op
 
 
