@@ -50,12 +50,53 @@ def cortes(order_id: np.ndarray, order_id_base: int, n_orders: int, world: int) 
     return out
 
 
-def fusionar(product_y_cliente, group=None) -> None:
+def fusionar(product_y_cliente, group=None, en_curso: bool = False):
     """In-place all-reduce (sum) of the concatenated [product_qty | customer_total_cents] tensor.
 
     `product_y_cliente` is a torch int64 tensor (CUDA with the RCCL backend, CPU with gloo).  A
     single-process run (no process group) leaves it unchanged.
+
+    With `en_curso` the collective is only started and its work handle returned (None when there is
+    nothing to exchange): the caller goes on with the next batch and calls `.wait()` on the handle before
+    it reads, or reuses, the tensor.  With RCCL that wait orders the caller's stream behind the
+    collective without blocking the host.
     """
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(product_y_cliente, op=dist.ReduceOp.SUM, group=group)
+        work = dist.all_reduce(product_y_cliente, op=dist.ReduceOp.SUM, group=group, async_op=en_curso)
+        return work if en_curso else None
+    return None
+
+
+class FusionEnCurso:
+    """The exchange step of batch i overlapped with the kernels of batch i + 1: two result buffers used
+    in turn; before a buffer is written again the all-reduce that last read it is waited for."""
+
+    def __init__(self, buffers, group=None):
+        self.buffers = list(buffers)
+        self.group = group
+        self._work = [None] * len(self.buffers)
+        self._turn = 0
+
+    def siguiente(self):
+        """The buffer of the next batch, free to be overwritten."""
+        i = self._turn % len(self.buffers)
+        if self._work[i] is not None:
+            self._work[i].wait()
+            self._work[i] = None
+        return self.buffers[i]
+
+    def lanzar(self):
+        """Start the all-reduce of the buffer handed out last; returns that buffer."""
+        i = self._turn % len(self.buffers)
+        self._work[i] = fusionar(self.buffers[i], self.group, en_curso=True)
+        self._turn += 1
+        return self.buffers[i]
+
+    def esperar(self):
+        """Wait for every exchange still in flight; returns the buffer of the last batch."""
+        for i, w in enumerate(self._work):
+            if w is not None:
+                w.wait()
+                self._work[i] = None
+        return self.buffers[(self._turn - 1) % len(self.buffers)]

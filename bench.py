@@ -126,12 +126,21 @@ def main():
     dev = ds.order_id.device
     P, Cn = args.products, args.customers
     tot = torch.empty(ds.n_orders, dtype=torch.int64, device=dev)
-    merged = torch.empty(P + Cn, dtype=torch.int64, device=dev)      # [product_qty | customer_total_cents]
-    pq, ct = merged[:P], merged[P:]
+    # [product_qty | customer_total_cents] of a step.  With more than one rank the all-reduce of step i
+    # runs on RCCL's stream while the kernels of step i + 1 run on this one, so two buffers take turns
+    # (ACMPC_BENCH_OVERLAP=0: one buffer, the all-reduce waited for inside the step).
+    overlap = world > 1 and backend == "nccl" and os.environ.get("ACMPC_BENCH_OVERLAP", "1") != "0"
+    bufs = [torch.empty(P + Cn, dtype=torch.int64, device=dev) for _ in range(2 if overlap else 1)]
+    turnos = reparto.FusionEnCurso(bufs) if overlap else None
+    merged = bufs[0]
 
     def step():
-        motor.agregar_device(ds.order_id, ds.product_idx, ds.qty, ds.order_customer, ds.order_id_base, Cn, tot, pq, ct)
-        if world > 1:
+        buf = turnos.siguiente() if overlap else merged
+        motor.agregar_device(ds.order_id, ds.product_idx, ds.qty, ds.order_customer, ds.order_id_base, Cn, tot,
+                             buf[:P], buf[P:])
+        if overlap:
+            turnos.lanzar()
+        elif world > 1:
             if backend == "nccl":
                 reparto.fusionar(merged)
             else:
@@ -140,6 +149,8 @@ def main():
                 merged.copy_(host)
 
     def fence():
+        if overlap:
+            turnos.esperar()                 # every step's exchange is complete inside the timed region
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -161,6 +172,8 @@ def main():
     assert motor.estado() == 0
 
     # sanity on the result of the last step (cheap, outside the timed region): every line counted once
+    last = turnos.esperar() if overlap else merged
+    pq, ct = last[:P], last[P:]
     total_qty = int(pq.sum().item())
     assert total_qty == n_total, (total_qty, n_total)
 

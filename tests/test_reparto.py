@@ -99,3 +99,62 @@ def test_two_rank_gloo_merge_equals_unsharded(oracle):
     np.testing.assert_array_equal(np.concatenate([r[3] for r in results]), etot)     # totals stay local
     for r in results:
         np.testing.assert_array_equal(r[4], np.concatenate([epq, ect]))              # every rank holds the merge
+
+
+def _pipeline_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from ac_mpc_amd import reparto as rp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bufs = [torch.zeros(1000, dtype=torch.int64) for _ in range(2)]
+        turnos = rp.FusionEnCurso(bufs)
+        seen = []
+        for step in range(5):
+            buf = turnos.siguiente()                 # waits for the exchange of step - 2, which used this buffer
+            if step >= 2:
+                seen.append(buf.clone())             # ... so its merged values are all there
+            buf.copy_(torch.arange(1000, dtype=torch.int64) * (rank + 1) + step)
+            turnos.lanzar()
+        last = turnos.esperar()
+        q.put((rank, [s.numpy() for s in seen], last.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_overlapped_merge_keeps_every_step():
+    """The exchange of step i stays in flight during step i + 1: two buffers in turn, each waited for
+    before it is written again, all of them at the end."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    base = np.arange(1000, dtype=np.int64)
+    merged = lambda step: base * 3 + 2 * step        # rank 0: base + step, rank 1: 2 * base + step
+    for _, seen, last in results:
+        for k, got in enumerate(seen):               # buffers handed back at steps 2, 3, 4 hold steps 0, 1, 2
+            np.testing.assert_array_equal(got, merged(k))
+        np.testing.assert_array_equal(last, merged(4))
+
+
+def test_overlapped_merge_without_a_process_group_is_a_no_op():
+    import torch
+    from ac_mpc_amd import reparto as rp
+    bufs = [torch.arange(4, dtype=torch.int64), torch.zeros(4, dtype=torch.int64)]
+    turnos = rp.FusionEnCurso(bufs)
+    assert turnos.siguiente() is bufs[0]
+    assert turnos.lanzar() is bufs[0]
+    assert turnos.siguiente() is bufs[1]
+    turnos.lanzar()
+    assert turnos.esperar() is bufs[1] and bufs[0].tolist() == [0, 1, 2, 3]
