@@ -10,6 +10,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+# A longer campaign on the GPU box: ACMPC_FUZZ_SEED shifts every seed, ACMPC_FUZZ_SCALE multiplies the trials.
+SEED = int(os.environ.get("ACMPC_FUZZ_SEED", "0"))
+SCALE = int(os.environ.get("ACMPC_FUZZ_SCALE", "1"))
+
 
 def _case(rng):
     n_orders = int(rng.integers(1, 400))
@@ -70,8 +74,8 @@ def test_random_small_inputs(oracle, fuse, order):
         else:
             os.environ["ACMPC_FUSE"] = old
     m.orden_lineas(order)
-    rng = np.random.default_rng(1000 + int(fuse) * 10 + (0 if order is False else 1 if order is True else 2))
-    for trial in range(300):
+    rng = np.random.default_rng(SEED + 1000 + int(fuse) * 10 + (0 if order is False else 1 if order is True else 2))
+    for trial in range(300 * SCALE):
         k = _case(rng)
         oid, pidx, qty = k["oid"], k["pidx"], k["qty"]
         lp = k["life"].get("line_price")
@@ -107,8 +111,8 @@ def test_random_medium_inputs_with_poisoned_outputs(oracle, fuse):
         else:
             os.environ["ACMPC_FUSE"] = old
     dev = torch.device("cuda", 0)
-    rng = np.random.default_rng(77 + int(fuse))
-    for trial in range(30):
+    rng = np.random.default_rng(SEED + 77 + int(fuse))
+    for trial in range(30 * SCALE):
         n_lines = int(rng.choice([1, 255, 256, 257, 4096, 65_536, 300_001, 1_048_576, 3_000_000]))
         density = rng.choice([0.02, 0.25, 1.0, 30.0])            # orders per line
         n_orders = min(8_000_000, max(1, int(n_lines * density) + int(rng.integers(0, 50))))
@@ -163,11 +167,11 @@ def test_text_paths_with_poisoned_device_buffers(oracle):
     from tests import ingest_cases as ic
     m = MotorLote(0)
     dev = torch.device("cuda", 0)
-    rng = np.random.default_rng(91)
+    rng = np.random.default_rng(SEED + 91)
     p = 500
     codes = [ic.code_of(i) for i in range(p)]
     ingesta.cargar_codigos(m, codes)
-    for trial in range(12):
+    for trial in range(12 * SCALE):
         n = int(rng.choice([0, 1, 700, 20_000, 250_000]))
         oid = np.sort(rng.integers(5, 5 + max(1, n // 3), size=n)).astype(np.int32)
         pidx = rng.integers(-1, p, size=n).astype(np.int32)

@@ -8,6 +8,7 @@ from ac_mpc_amd import ErrorLote, _lib, ingesta
 from tests import ingest_cases as ic
 
 pytestmark = pytest.mark.gpu
+SEED = int(os.environ.get("ACMPC_FUZZ_SEED", "0"))       # shifts the seeds of the generated texts
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -70,7 +71,7 @@ def test_empty_and_header_only_text(motor, oracle):
 def test_fuzzed_text_row_for_row(motor, oracle):
     """Random corrupted lines: the device must classify and parse every line exactly like the oracle."""
     import ctypes as C
-    rng = np.random.default_rng(43)
+    rng = np.random.default_rng(SEED + 43)
     alphabet = list(b"0123456789 ,'\"()-;\t\rabSKU-x")
     codes = ["1", "2", "3", "ab", "SKU-1", "a b", "abcdefghijklmnopqrstuvwxyz0123"]
     lines = []
@@ -105,7 +106,7 @@ def test_fuzzed_bytes_full_alphabet(motor, oracle):
     """Every byte value (a vertical tab or 0x01 right after a newline must not look like a line start),
     leading zeros, 9 to 12 digit numbers around the int32 limits, rows of 119 to 122 bytes."""
     import ctypes as C
-    rng = np.random.default_rng(47)
+    rng = np.random.default_rng(SEED + 47)
     codes = ["1", "2", "ab", "SKU-1", "x" * 30, "\x0b5", "caf\xe9"]
     lines = []
     for i in range(80_000):
@@ -143,7 +144,7 @@ def test_fuzzed_bytes_full_alphabet(motor, oracle):
 def test_dense_rows_empty_chunks_and_long_rows_keep_their_order(motor, oracle):
     """Row bases come from a look-back over the chunks before: mix chunks with thousands of tiny rows (more
     than a chunk can park), chunks without any data row and chunks of long rows, over many chunks."""
-    rng = np.random.default_rng(53)
+    rng = np.random.default_rng(SEED + 53)
     codes = ["1", "2", "3"]
     parts = []
     k = 0
