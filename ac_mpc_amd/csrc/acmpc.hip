@@ -294,9 +294,9 @@ int clear_carries(acmpc_ctx* ctx, hipStream_t st) {
   return ACMPC_OK;
 }
 
-template <typename PriceT, bool kLds, int LPL, bool kLife = false>
+template <typename PriceT, bool kLds, int LPL, bool kLife = false, bool kSnap = false>
 int launch_lines(acmpc_ctx* ctx, const LinesPlan& pl, const LinesArgs& a, hipStream_t st) {
-  auto kern = k_lines<PriceT, kLds, LPL, kLife>;
+  auto kern = k_lines<PriceT, kLds, LPL, kLife, kSnap>;
   {
     int rc = set_dyn_lds(ctx, kern, pl.lds_bytes);
     if (rc) return rc;
@@ -431,7 +431,10 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       else rc = launch_lines_any<int64_t, true>(ctx, lp, tables, a, st);
     }
     else if (life_lines) {
-      if (!lp.lds_tables) rc = launch_lines<int64_t, false, 4, true>(ctx, lp, a, st);
+      // with a line-price column the price table is not read: one price type serves
+      if (d_line_price) rc = lp.lds_tables ? launch_lines<int64_t, true, 4, true, true>(ctx, lp, a, st)
+                                           : launch_lines<int64_t, false, 4, true, true>(ctx, lp, a, st);
+      else if (!lp.lds_tables) rc = launch_lines<int64_t, false, 4, true>(ctx, lp, a, st);
       else if (lp.price32) rc = launch_lines<int32_t, true, 4, true>(ctx, lp, a, st);
       else rc = launch_lines<int64_t, true, 4, true>(ctx, lp, a, st);
     }

@@ -79,19 +79,25 @@ struct LinesArgs {
 
 // Lifecycle: quantities that reach the stock delta (0 for lines of orders that do not count).
 template <int LPL>
-__device__ __forceinline__ void live_quantities(const LinesArgs& a, const int (&ids)[LPL], const int (&qs)[LPL],
-                                                int (&qh)[LPL]) {
+__device__ __forceinline__ void load_states(const LinesArgs& a, const int (&ids)[LPL], uint32_t (&s)[LPL]) {
   if (a.order_state) {
     const uint32_t top = (uint32_t)a.n_orders - 1u;         // n_orders > 0 whenever there are lines
-    unsigned char s[LPL];
 #pragma unroll
     for (int i = 0; i < LPL; ++i) s[i] = a.order_state[min((uint32_t)ids[i] - (uint32_t)a.base, top)];
-#pragma unroll
-    for (int i = 0; i < LPL; ++i) qh[i] = (s[i] & 1) ? qs[i] : 0;
   } else {
 #pragma unroll
-    for (int i = 0; i < LPL; ++i) qh[i] = qs[i];
+    for (int i = 0; i < LPL; ++i) s[i] = 1u;
   }
+}
+
+// The quantities that reach the stock delta: those of lines whose order counts (bit 0 of its state).
+// Loading the states (load_states) is kept apart so that a tile loop can issue those loads before the
+// next tile's: vector loads return in order, and a wait for the states would otherwise be a wait for the
+// tile that was just requested.
+template <int LPL>
+__device__ __forceinline__ void live_quantities(const int (&qs)[LPL], const uint32_t (&s)[LPL], int (&qh)[LPL]) {
+#pragma unroll
+  for (int i = 0; i < LPL; ++i) qh[i] = (s[i] & 1u) ? qs[i] : 0;
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
@@ -199,13 +205,16 @@ __device__ __forceinline__ void stage_flush(const LinesArgs& a, long long* s_sta
 // cell.  Any product_idx outside [0, P) is clamped to it with one unsigned min, so unknown codes
 // need no branch and add nothing.
 //
-// kLife: `qh` holds the quantities that reach the stock delta (see live_quantities) and, when `snap`
-// is not null, snap[i] is the line's own price; otherwise qh is qs and the table price is used.
+// kLife: `qh` holds the quantities that reach the stock delta (see live_quantities) and, when `snapped`,
+// snap[i] is the line's own price; otherwise qh is qs and the table price is used.  (snap is an array
+// reference, not a pointer: indexed through a pointer that may be null the prices end up in scratch
+// memory, and waiting for a scratch load also waits for the next tile's loads, which were issued first.)
 template <typename PriceT, bool kLdsTables, int LPL, bool kLife = false>
 __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_price, uint32_t* s_hist,
                                            long long* s_stage, const int (&ids)[LPL], const int (&prs)[LPL],
                                            const int (&qs)[LPL], int lane, uint32_t lt_lo, uint32_t lt_hi,
-                                           WaveRun& o, const int (&qh)[LPL], const long long* snap = nullptr) {
+                                           WaveRun& o, const int (&qh)[LPL], const long long (&snap)[LPL],
+                                           bool snapped) {
   const uint32_t P = (uint32_t)a.n_products;
   uint32_t pi[LPL];
   long long v[LPL];
@@ -222,7 +231,7 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
       __hip_atomic_fetch_add(&s_hist[pi[i]], (uint32_t)qh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       qmax = max(qmax, (uint32_t)qh[i]);
     }
-    if (kLife && snap) {
+    if (kLife && snapped) {
 #pragma unroll
       for (int i = 0; i < LPL; ++i) v[i] = (pi[i] < P ? snap[i] : 0ll) * (long long)qs[i];
     } else {
@@ -235,7 +244,7 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
   } else {
 #pragma unroll
     for (int i = 0; i < LPL; ++i) {
-      const long long pr = (kLife && snap) ? (pi[i] < P ? snap[i] : 0ll) : a.price[pi[i]];
+      const long long pr = (kLife && snapped) ? (pi[i] < P ? snap[i] : 0ll) : a.price[pi[i]];
       v[i] = pr * (long long)qs[i];
       if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qh[i]);
     }
@@ -397,9 +406,14 @@ __device__ __forceinline__ void load_prices(const long long* p, long long (&out)
   }
 }
 
-template <typename PriceT, bool kLdsTables, int LPL, bool kLife = false>
+// kSnap (lifecycle only): the line-price column is present.  A template parameter rather than a test of
+// the pointer, so that the loads of that column and their uses are on one path for the compiler: with a
+// run-time test it has to assume that a load into the same registers may still be pending from a path
+// that never happens, and waits for it (and for everything requested before it) in the middle of the loop.
+template <typename PriceT, bool kLdsTables, int LPL, bool kLife = false, bool kSnap = false>
 __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
   static_assert(!kLife || LPL == 4, "lifecycle columns are read four lines per lane");
+  static_assert(kLife || !kSnap, "line prices are a lifecycle column");
   constexpr int kTileL = kWave * LPL;                 // lines per wave-tile
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
@@ -453,7 +467,7 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
       long long off = t0 * kTileL + lane * LPL;
       int nid[LPL], npr[LPL], nq[LPL];
       int4 nraw[2] = {};
-      const bool snapped = kLife && a.line_price != nullptr;
+      constexpr bool snapped = kSnap;
       load_lines<LPL>(a.order_id + off, nid);
       load_lines<LPL>(a.product_idx + off, npr);
       load_lines<LPL>(a.qty + off, nq);
@@ -463,22 +477,29 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
       int until_burst = a.burst;
       for (long long t = t0; t <= last; ++t) {
         int ids[LPL], prs[LPL], qs[LPL];
-        long long sn[4];
+        long long sn[LPL] = {};
 #pragma unroll
         for (int i = 0; i < LPL; ++i) { ids[i] = nid[i]; prs[i] = npr[i]; qs[i] = nq[i]; }
         if constexpr (kLife) { if (snapped) own_prices(s_xpose, lane, nraw, sn); }
+        uint32_t stt[LPL];
+        if constexpr (kLife) load_states<LPL>(a, ids, stt);      // before the next tile's loads: see live_quantities
         off += (t < last) ? kTileL : 0;
         load_lines<LPL>(a.order_id + off, nid);
         load_lines<LPL>(a.product_idx + off, npr);
         load_lines<LPL>(a.qty + off, nq);
         if constexpr (kLife) { if (snapped) load_prices_raw(a.line_price + (off - lane * LPL), lane, nraw); }
         if constexpr (kLife) {
+          // keep the uses of the states behind the loads just issued (the scheduler would otherwise move
+          // them, and the wait for the states, in front of the next tile's loads)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < LPL; ++i) asm volatile("" : "+v"(stt[i]));   // the states are first looked at here
           int qh[LPL];
-          live_quantities<LPL>(a, ids, qs, qh);
+          live_quantities<LPL>(qs, stt, qh);
           lines_tile<PriceT, kLdsTables, LPL, true>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qh,
-                                                    snapped ? sn : nullptr);
+                                                    sn, snapped);
         } else {
-          lines_tile<PriceT, kLdsTables, LPL>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs);
+          lines_tile<PriceT, kLdsTables, LPL>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs, sn, false);
         }
         if (bursts && --until_burst == 0) {
           until_burst = a.burst;
@@ -503,14 +524,17 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
       if constexpr (kLife) {
         long long sn[LPL];
         int qh[LPL];
-        const bool snapped = a.line_price != nullptr;
+        constexpr bool snapped = kSnap;
 #pragma unroll
         for (int i = 0; i < LPL; ++i) sn[i] = (snapped && l0 + i < a.n_lines) ? a.line_price[l0 + i] : 0ll;
-        live_quantities<LPL>(a, ids, qs, qh);
+        uint32_t stt[LPL];
+        load_states<LPL>(a, ids, stt);
+        live_quantities<LPL>(qs, stt, qh);
         lines_tile<PriceT, kLdsTables, LPL, true>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qh,
-                                                  snapped ? sn : nullptr);
+                                                  sn, snapped);
       } else {
-        lines_tile<PriceT, kLdsTables, LPL>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs);
+        const long long none[LPL] = {};
+        lines_tile<PriceT, kLdsTables, LPL>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs, none, false);
       }
     }
     // orders closed since the last flush (everything below the order that is still open)
@@ -599,8 +623,11 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
         sn[i] = (snapped && in) ? a.line_price[l0 + i] : 0ll;
       }
     }
-    if (kLife) live_quantities<LPL>(a, ids, qs, qh);
-    else {
+    if (kLife) {
+      uint32_t stt[LPL];
+      load_states<LPL>(a, ids, stt);
+      live_quantities<LPL>(qs, stt, qh);
+    } else {
 #pragma unroll
       for (int i = 0; i < LPL; ++i) qh[i] = qs[i];
     }

@@ -143,6 +143,36 @@ __global__ void __launch_bounds__(1024) k_probe(const int* __restrict__ a, const
   if (acc == 0x7fffffff) *sink = acc;
 }
 
+
+// Four input streams: three int32 columns and one int64 column (the line-price column of the lifecycle
+// path), k_lines mapping (a contiguous run of tiles per wave), one tile ahead, 8 B written per 4 lines.
+__global__ void __launch_bounds__(1024) k_probe4(const int* __restrict__ a, const int* __restrict__ b,
+                                                 const int* __restrict__ c, const int* __restrict__ d8,
+                                                 long long n_tiles, long long* __restrict__ out, int* sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const long long n_waves = (long long)gridDim.x * wpb;
+  const long long g = (long long)blockIdx.x * wpb + wave;
+  const long long per = (n_tiles + n_waves - 1) / n_waves;
+  const long long tb = g * per;
+  long long te = tb + per; if (te > n_tiles) te = n_tiles;
+  if (tb >= te) return;
+  int acc = 0;
+  long long off = tb * kTile + lane * 4;
+  int4 xa = ntload4(a + off), xb = ntload4(b + off), xc = ntload4(c + off);
+  int4 xd = ntload4(d8 + tb * kTile * 2 + lane * 4), xe = ntload4(d8 + tb * kTile * 2 + 256 + lane * 4);
+  for (long long t = tb; t < te; ++t) {
+    const long long tn = t + 1 < te ? t + 1 : t;
+    const long long offn = tn * kTile + lane * 4;
+    const int4 ya = ntload4(a + offn), yb = ntload4(b + offn), yc = ntload4(c + offn);
+    const int4 yd = ntload4(d8 + tn * kTile * 2 + lane * 4), ye = ntload4(d8 + tn * kTile * 2 + 256 + lane * 4);
+    const int f = fold(xa, xb, xc) + (xd.x ^ xd.z) + (xe.y ^ xe.w);
+    acc += f;
+    out[t * 64 + lane] = f;
+    xa = ya; xb = yb; xc = yc; xd = yd; xe = ye;
+  }
+  if (acc == 0x7fffffff) *sink = acc;
+}
+
 __global__ void __launch_bounds__(256) k_fill(int4* dst, long long n4) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) dst[i] = make_int4(1, 2, 3, (int)i);
 }
@@ -244,6 +274,19 @@ int main(int argc, char** argv) {
     run_sib<2, false>(4, 256, 512, a, out, m, sink);
     run_sib<4, false>(4, 512, 512, a, out, m, sink);
     run_sib<4, false>(8, 512, 512, a, out, m, sink);
+  }
+  if (argc > 2 && argv[2][0] == '4') {
+    int* d8;
+    CK(hipMalloc(&d8, n * 8 + 4096)); CK(hipMemset(d8, 5, n * 8));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0));
+      for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(k_probe4, dim3(256), dim3(1024), 0, 0, a, b, c, d8, n / kTile, out, sink);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+      printf("four streams (3 x int32 + int64 per line) + 8 B per 4 lines written: %.3f ms  %.2f TB/s\n", ms, 22.0 * n / ms / 1e9);
+    }
+    return 0;
   }
   if (argc > 2) return 0;
 #define RUN(M, D, W, BL, TH) run<M, D, W>(#M "/" #D " write-mode " #W, BL, TH, a, b, c, n, out, sink);
