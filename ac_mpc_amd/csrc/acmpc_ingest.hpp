@@ -492,125 +492,125 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
     const int64_t c_first = (int64_t)s_ticket * kIngPerTicket;
     if (c_first >= a.n_chunks) break;                      // uniform
     for (int part = 0; part < kIngPerTicket; ++part) {
-    const int64_t c = c_first + part;
-    if (c >= a.n_chunks) break;                            // uniform
-    const int64_t cbase = c * kIngChunk;
-    // stage chunk + lookahead (16-byte pieces; the text buffer is padded by the host side)
-    const int64_t avail = a.n_bytes - cbase;
-    const int want = (int)(avail < kIngChunk + kIngLook ? avail : kIngChunk + kIngLook);
-    for (int o = tid * 16; o < want && !((a.ablate & 16) && c >= (int64_t)gridDim.x); o += kIngThreads * 16) {
-      if (o + 16 <= want) {
-        *reinterpret_cast<uint4*>(s_chunk + o) = *reinterpret_cast<const uint4*>(a.text + cbase + o);
-      } else {
-        for (int b = o; b < want; ++b) s_chunk[b] = a.text[cbase + b];
-      }
-    }
-    if (tid == 0) s_chunk[want] = (unsigned char)'\n';     // sentinel: every row ends in a newline
-    // the 16 bytes in front of the chunk come along (the first thread needs the byte before its slice)
-    if (tid == kIngThreads - 1 && c > 0) *reinterpret_cast<uint4*>(s_text) = *reinterpret_cast<const uint4*>(a.text + cbase - kIngFront);
-    __syncthreads();
-    const int64_t base = cbase + (int64_t)tid * kIngPerThread;
-    // line starts in this thread's slice, then the data rows among them (first one or two bytes)
-    const int o = tid * kIngPerThread;
-    unsigned long long dmask = 0;
-    if (base < a.n_bytes) {
-      uint32_t w[kIngWords];
-#pragma unroll
-      for (int j = 0; j < kIngWords / 4; ++j) {
-        // whole 16-byte pieces even at the end of the text: what lies past the last byte (the sentinel,
-        // leftovers of an earlier chunk) only sets mask bits that are cleared below
-        const uint4 v = *reinterpret_cast<const uint4*>(s_chunk + o + 16 * j);
-        w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
-      }
-      const uint32_t prev = base == 0 ? (uint32_t)'\n' : (uint32_t)s_chunk[o - 1];
-      unsigned long long smask = ing_line_start_mask(w, prev);
-      const int64_t left = a.n_bytes - base;                 // bytes of text from this thread's first byte on
-      if (left < kIngPerThread) smask &= (1ull << left) - 1ull;
-      for (unsigned long long m = smask; m; m &= m - 1ull) {
-        const int k = __ffsll((long long)m) - 1;
-        const uint32_t c0 = s_chunk[o + k];
-        const uint32_t c1 = k + 1 < left ? (uint32_t)s_chunk[o + k + 1] : 0u;
-        if (ing_data_row(c0, c1)) dmask |= 1ull << k;
-      }
-    }
-    const int cnt = __popcll(dmask);
-    // rank of this thread's first row inside the chunk
-    int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    int woff = 0, n_r = 0;
-#pragma unroll
-    for (int k = 0; k < kIngThreads / 64; ++k) { if (k < wave) woff += s_w[k]; n_r += s_w[k]; }
-    // publish as early as possible: successors add this count up long before this chunk knows its base
-    if (tid == 0 && !(a.ablate & 64)) ing_publish_own(a.chunk_state, c, n_r);
-    // a long row list would run into the parked columns of the chunk before: write those out first
-    if (n_r > kKeep) { flush_parked(); __syncthreads(); }  // (uniform) every thread has read its parked rows back
-    // hand the rows out one per thread: every lane of a wave then parses a row of its own, and
-    // consecutive lanes write consecutive output rows
-    int r = woff + incl - cnt;
-    for (unsigned long long m = dmask; m; m &= m - 1ull, ++r) s_row[r] = (unsigned short)(o + __ffsll((long long)m) - 1);
-    __syncthreads();
-    if (n_r <= kKeep) {
-      flush_parked();                                      // the chunk before: its look-back comes late, after this publish
-      // A thread steps two rows through the automaton at once while more than one batch of rows is left
-      // (the table look-ups of a row depend on each other; a second row fills the waits), one otherwise.
-      auto parse_batch = [&](auto together, int r0) {
-        constexpr int kTogether = decltype(together)::value;
-        int p[kTogether];
-        uint32_t st16[kTogether], A[kTogether], B[kTogether];
-#pragma unroll
-        for (int q = 0; q < kTogether; ++q) {                // a missing row repeats the thread's first
-          const int rq = r0 + q * kIngThreads;
-          p[q] = kIngFront + (int)s_row[rq < n_r ? rq : r0];
-        }
-        if (a.ablate & 4) {
-#pragma unroll
-          for (int q = 0; q < kTogether; ++q) { st16[q] = sDone * kNumClasses; A[q] = 0x01000000u | (uint32_t)p[q]; B[q] = 0; }
+      const int64_t c = c_first + part;
+      if (c >= a.n_chunks) break;                            // uniform
+      const int64_t cbase = c * kIngChunk;
+      // stage chunk + lookahead (16-byte pieces; the text buffer is padded by the host side)
+      const int64_t avail = a.n_bytes - cbase;
+      const int want = (int)(avail < kIngChunk + kIngLook ? avail : kIngChunk + kIngLook);
+      for (int o = tid * 16; o < want && !((a.ablate & 16) && c >= (int64_t)gridDim.x); o += kIngThreads * 16) {
+        if (o + 16 <= want) {
+          *reinterpret_cast<uint4*>(s_chunk + o) = *reinterpret_cast<const uint4*>(a.text + cbase + o);
         } else {
-          ing_scan_rows<kTogether>(s_text, s_ct, s_T, p, st16, A, B);
+          for (int b = o; b < want; ++b) s_chunk[b] = a.text[cbase + b];
         }
-#pragma unroll
-        for (int q = 0; q < kTogether; ++q) {
-          const int rq = r0 + q * kIngThreads;
-          if (rq < n_r) {
-            int32_t oid = 0, pidx = -1, qty = 0;
-            // the cheaper conversion when no row of the wave has a long number or a long code
-            const uint32_t Aq = A[q];
-            const bool plain = ((Aq >> kANd1) & 127u) <= 8u && ((Aq >> kANd2) & 127u) <= 4u && ((Aq >> kACl) & 127u) <= 12u;
-            bool ok = true;
-            if (!(a.ablate & 1)) {
-              if (__ballot(!plain) == 0ull) ok = ing_finish_row<2, 1, 3>(s_text, p[q], st16[q], Aq, B[q], a, oid, pidx, qty);
-              else ok = ing_finish_row<3, 3, 8>(s_text, p[q], st16[q], Aq, B[q], a, oid, pidx, qty);
-            }
-            if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
-            s_res[rq] = oid; s_res[kKeep + rq] = pidx; s_res[2 * kKeep + rq] = qty;
-          }
-        }
-      };
-      int b0 = 0;                                            // first row of the batch (uniform)
-      for (; n_r - b0 > kIngThreads; b0 += 2 * kIngThreads)
-        if (b0 + tid < n_r) parse_batch(std::integral_constant<int, 2>{}, b0 + tid);
-      if (b0 + tid < n_r) parse_batch(std::integral_constant<int, 1>{}, b0 + tid);
-      c_parked = c;
-      n_parked = n_r;
-    } else {
-      // more rows than can be parked (rows of a few bytes): look back first, write as they are parsed
-      resolve_base(c, n_r);
-      const long long rbase = s_base;
-      for (r = tid; r < n_r; r += kIngThreads) {
-        int32_t oid = 0, pidx = -1, qty = 0;
-        const int p[1] = {kIngFront + (int)s_row[r]};
-        uint32_t st16[1], A[1], B[1];
-        ing_scan_rows<1>(s_text, s_ct, s_T, p, st16, A, B);
-        const bool ok = ing_finish_row<3, 3, 8>(s_text, p[0], st16[0], A[0], B[0], a, oid, pidx, qty);
-        if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
-        const long long row = rbase + r;
-        if (row < a.capacity) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }
       }
-    }
-    __syncthreads();                                       // the text and the row list are free again
+      if (tid == 0) s_chunk[want] = (unsigned char)'\n';     // sentinel: every row ends in a newline
+      // the 16 bytes in front of the chunk come along (the first thread needs the byte before its slice)
+      if (tid == kIngThreads - 1 && c > 0) *reinterpret_cast<uint4*>(s_text) = *reinterpret_cast<const uint4*>(a.text + cbase - kIngFront);
+      __syncthreads();
+      const int64_t base = cbase + (int64_t)tid * kIngPerThread;
+      // line starts in this thread's slice, then the data rows among them (first one or two bytes)
+      const int o = tid * kIngPerThread;
+      unsigned long long dmask = 0;
+      if (base < a.n_bytes) {
+        uint32_t w[kIngWords];
+#pragma unroll
+        for (int j = 0; j < kIngWords / 4; ++j) {
+          // whole 16-byte pieces even at the end of the text: what lies past the last byte (the sentinel,
+          // leftovers of an earlier chunk) only sets mask bits that are cleared below
+          const uint4 v = *reinterpret_cast<const uint4*>(s_chunk + o + 16 * j);
+          w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+        }
+        const uint32_t prev = base == 0 ? (uint32_t)'\n' : (uint32_t)s_chunk[o - 1];
+        unsigned long long smask = ing_line_start_mask(w, prev);
+        const int64_t left = a.n_bytes - base;                 // bytes of text from this thread's first byte on
+        if (left < kIngPerThread) smask &= (1ull << left) - 1ull;
+        for (unsigned long long m = smask; m; m &= m - 1ull) {
+          const int k = __ffsll((long long)m) - 1;
+          const uint32_t c0 = s_chunk[o + k];
+          const uint32_t c1 = k + 1 < left ? (uint32_t)s_chunk[o + k + 1] : 0u;
+          if (ing_data_row(c0, c1)) dmask |= 1ull << k;
+        }
+      }
+      const int cnt = __popcll(dmask);
+      // rank of this thread's first row inside the chunk
+      int incl = cnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+      if (lane == 63) s_w[wave] = incl;
+      __syncthreads();
+      int woff = 0, n_r = 0;
+#pragma unroll
+      for (int k = 0; k < kIngThreads / 64; ++k) { if (k < wave) woff += s_w[k]; n_r += s_w[k]; }
+      // publish as early as possible: successors add this count up long before this chunk knows its base
+      if (tid == 0 && !(a.ablate & 64)) ing_publish_own(a.chunk_state, c, n_r);
+      // a long row list would run into the parked columns of the chunk before: write those out first
+      if (n_r > kKeep) { flush_parked(); __syncthreads(); }  // (uniform) every thread has read its parked rows back
+      // hand the rows out one per thread: every lane of a wave then parses a row of its own, and
+      // consecutive lanes write consecutive output rows
+      int r = woff + incl - cnt;
+      for (unsigned long long m = dmask; m; m &= m - 1ull, ++r) s_row[r] = (unsigned short)(o + __ffsll((long long)m) - 1);
+      __syncthreads();
+      if (n_r <= kKeep) {
+        flush_parked();                                      // the chunk before: its look-back comes late, after this publish
+        // A thread steps two rows through the automaton at once while more than one batch of rows is left
+        // (the table look-ups of a row depend on each other; a second row fills the waits), one otherwise.
+        auto parse_batch = [&](auto together, int r0) {
+          constexpr int kTogether = decltype(together)::value;
+          int p[kTogether];
+          uint32_t st16[kTogether], A[kTogether], B[kTogether];
+#pragma unroll
+          for (int q = 0; q < kTogether; ++q) {                // a missing row repeats the thread's first
+            const int rq = r0 + q * kIngThreads;
+            p[q] = kIngFront + (int)s_row[rq < n_r ? rq : r0];
+          }
+          if (a.ablate & 4) {
+#pragma unroll
+            for (int q = 0; q < kTogether; ++q) { st16[q] = sDone * kNumClasses; A[q] = 0x01000000u | (uint32_t)p[q]; B[q] = 0; }
+          } else {
+            ing_scan_rows<kTogether>(s_text, s_ct, s_T, p, st16, A, B);
+          }
+#pragma unroll
+          for (int q = 0; q < kTogether; ++q) {
+            const int rq = r0 + q * kIngThreads;
+            if (rq < n_r) {
+              int32_t oid = 0, pidx = -1, qty = 0;
+              // the cheaper conversion when no row of the wave has a long number or a long code
+              const uint32_t Aq = A[q];
+              const bool plain = ((Aq >> kANd1) & 127u) <= 8u && ((Aq >> kANd2) & 127u) <= 4u && ((Aq >> kACl) & 127u) <= 12u;
+              bool ok = true;
+              if (!(a.ablate & 1)) {
+                if (__ballot(!plain) == 0ull) ok = ing_finish_row<2, 1, 3>(s_text, p[q], st16[q], Aq, B[q], a, oid, pidx, qty);
+                else ok = ing_finish_row<3, 3, 8>(s_text, p[q], st16[q], Aq, B[q], a, oid, pidx, qty);
+              }
+              if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
+              s_res[rq] = oid; s_res[kKeep + rq] = pidx; s_res[2 * kKeep + rq] = qty;
+            }
+          }
+        };
+        int b0 = 0;                                            // first row of the batch (uniform)
+        for (; n_r - b0 > kIngThreads; b0 += 2 * kIngThreads)
+          if (b0 + tid < n_r) parse_batch(std::integral_constant<int, 2>{}, b0 + tid);
+        if (b0 + tid < n_r) parse_batch(std::integral_constant<int, 1>{}, b0 + tid);
+        c_parked = c;
+        n_parked = n_r;
+      } else {
+        // more rows than can be parked (rows of a few bytes): look back first, write as they are parsed
+        resolve_base(c, n_r);
+        const long long rbase = s_base;
+        for (r = tid; r < n_r; r += kIngThreads) {
+          int32_t oid = 0, pidx = -1, qty = 0;
+          const int p[1] = {kIngFront + (int)s_row[r]};
+          uint32_t st16[1], A[1], B[1];
+          ing_scan_rows<1>(s_text, s_ct, s_T, p, st16, A, B);
+          const bool ok = ing_finish_row<3, 3, 8>(s_text, p[0], st16[0], A[0], B[0], a, oid, pidx, qty);
+          if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
+          const long long row = rbase + r;
+          if (row < a.capacity) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }
+        }
+      }
+      __syncthreads();                                       // the text and the row list are free again
     }
   }
   flush_parked();
