@@ -77,10 +77,11 @@ typedef struct acmpc_ctx acmpc_ctx;
 int  acmpc_init(acmpc_ctx** out, int device);
 void acmpc_destroy(acmpc_ctx* ctx);
 
-/* Static or context-owned message of the last failure; never NULL. */
+/* Static or context-owned message of the last failure; never NULL.
+ * Replaces the text handed to die() at library/consulSQL.php:12,19,31,38,45. */
 const char* acmpc_last_error(const acmpc_ctx* ctx);
 
-/* "acmpc <major>.<minor> gfx950". */
+/* "acmpc <major>.<minor> gfx950".  No counterpart in the reference. */
 const char* acmpc_version(void);
 
 /*
@@ -129,6 +130,8 @@ int acmpc_aggregate(acmpc_ctx* ctx,
  * (a hipStream_t; NULL = the default stream) and the call returns without
  * waiting.  Uses a workspace owned by the context: calls on one context must
  * not overlap in time.  Contract violations are reported by acmpc_status().
+ * Replaces the same loops as acmpc_aggregate (process/carrito.php:12-18,
+ * process/confirmcompra.php:24,35-37) for callers that keep the columns in HBM.
  */
 int acmpc_aggregate_device(acmpc_ctx* ctx,
                            const int32_t* d_order_id, const int32_t* d_product_idx,
@@ -199,6 +202,9 @@ int acmpc_aggregate_lifecycle_device(acmpc_ctx* ctx,
  * Wait for `hip_stream`, then store in *flags the OR of ACMPC_ST_* bits raised
  * by device calls since the previous acmpc_status(), and clear them.
  * Returns ACMPC_OK when *flags == 0, ACMPC_E_DATA otherwise.
+ * Stands where the reference tests the result of mysqli_query and dies
+ * (library/consulSQL.php:18-19): the device calls only enqueue work, so their
+ * verdict on the data is collected here.
  */
 int acmpc_status(acmpc_ctx* ctx, void* hip_stream, uint32_t* flags);
 
@@ -228,12 +234,14 @@ int acmpc_set_option(acmpc_ctx* ctx, int option, int64_t value);
  * Kernel timing.  With profiling enabled every acmpc_aggregate_device() call
  * brackets each of its kernels with HIP events on the call's stream;
  * acmpc_last_kernel_ms() waits for them and returns the milliseconds of the
- * last call's kernels in ms[ACMPC_N_KERNELS].
+ * last call's kernels in ms[ACMPC_N_KERNELS].  No counterpart in the reference
+ * (measurement only).
  */
 int acmpc_set_profiling(acmpc_ctx* ctx, int enabled);
 int acmpc_last_kernel_ms(acmpc_ctx* ctx, float* ms);
 
-/* Launch geometry of the order-line pass: workgroups and waves per workgroup. */
+/* Launch geometry of the order-line pass: workgroups and waves per workgroup.
+ * No counterpart in the reference (reported by the benchmark). */
 int acmpc_lines_geometry(acmpc_ctx* ctx, int32_t* n_workgroups, int32_t* waves_per_workgroup);
 
 /*
@@ -275,11 +283,15 @@ int acmpc_host_free(acmpc_ctx* ctx, void* p);
  * write one row per line).
  * ---------------------------------------------------------------------- */
 
-/* Product code list: n_products entries of 32 bytes each, NUL padded, codes of at most 30 bytes,
- * in the same order as the price table of acmpc_set_products.  Host pointer. */
+/* Product code list: n_products entries of 32 bytes each, NUL padded, codes of at most 30 bytes
+ * (producto.CodigoProd, varchar(30) and primary key: store.sql:110,200), in the same order as the
+ * price table of acmpc_set_products.  Host pointer.  Replaces the match on CodigoProd that the
+ * reference leaves to MariaDB (process/carrito.php:13). */
 int acmpc_set_product_codes(acmpc_ctx* ctx, const char* codes32, int32_t n_products);
 
-/* Parse n_bytes of DEVICE text (16-byte aligned) into DEVICE columns of capacity_rows entries.
+/* Reads back what consultasSQL::InsertSQL("detalle", ...) wrote (process/confirmcompra.php:36 through
+ * library/consulSQL.php:29-30; the reference itself has no reader of `detalle`).
+ * Parse n_bytes of DEVICE text (16-byte aligned) into DEVICE columns of capacity_rows entries.
  * *d_n_rows (device int64) receives the number of data rows found (rows beyond capacity_rows are
  * counted but not stored, and raise ACMPC_ST_INGEST_CAPACITY).  Enqueued on hip_stream. */
 int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, int64_t n_bytes,
