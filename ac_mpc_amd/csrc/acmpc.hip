@@ -195,6 +195,7 @@ int set_dyn_lds(acmpc_ctx* ctx, K kernel, size_t bytes) {
 
 struct LinesPlan {
   bool lds_tables;
+  bool price_lds;          // the price table is in LDS too (not with line prices, not when only the histogram fits)
   bool price32;
   size_t lds_bytes;
   int threads, blocks, waves_per_block;
@@ -211,6 +212,7 @@ int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p, bool line_pr
   // tables hold P + 1 entries (the null product): int32 or int64 prices + 32-bit histogram
   const size_t need32 = (size_t)ctx->p_pad * 8, need64 = (size_t)ctx->p_pad * 12;
   p->price32 = ctx->price_fits32;
+  p->price_lds = !line_prices;
   p->lds_bytes = line_prices ? (size_t)ctx->p_pad * 4 : p->price32 ? need32 : need64;
   p->threads = ctx->k1_threads;
   p->waves_per_block = p->threads / kWave;
@@ -221,7 +223,18 @@ int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p, bool line_pr
     return (size_t)p->waves_per_block * ((cap + kWave) * 8 + (line_prices ? 2048 : 0));
   };
   p->lds_tables = !ctx->force_global_tables && p->lds_bytes + stage_bytes(kTile) + kLdsReserve <= (size_t)kMaxLds;
-  if (!p->lds_tables) { p->lds_bytes = 0; p->price32 = false; p->lpl = 4; p->tile_lines = kTile; }
+  if (!p->lds_tables && !ctx->force_global_tables && !line_prices &&
+      (size_t)ctx->p_pad * 4 + stage_bytes(kTile) + kLdsReserve <= (size_t)kMaxLds) {
+    // the stock-delta histogram alone still fits: keep it in LDS (the alternative is one global atomic per
+    // line) and gather the prices from global memory, where a table of this size stays in L2
+    p->lds_tables = true;
+    p->price_lds = false;
+    p->price32 = false;
+    p->lds_bytes = (size_t)ctx->p_pad * 4;
+    p->lpl = 4;
+    p->tile_lines = kTile;
+  }
+  if (!p->lds_tables) { p->lds_bytes = 0; p->price32 = false; p->price_lds = false; p->lpl = 4; p->tile_lines = kTile; }
   p->stage_cap = 512;
   while (p->stage_cap > (uint32_t)kTile && p->lds_bytes + stage_bytes(p->stage_cap) + kLdsReserve > (size_t)kMaxLds)
     p->stage_cap >>= 1;
@@ -294,9 +307,9 @@ int clear_carries(acmpc_ctx* ctx, hipStream_t st) {
   return ACMPC_OK;
 }
 
-template <typename PriceT, bool kLds, int LPL, bool kLife = false, bool kSnap = false>
+template <typename PriceT, bool kLds, int LPL, bool kLife = false, bool kSnap = false, bool kPriceGlobal = false>
 int launch_lines(acmpc_ctx* ctx, const LinesPlan& pl, const LinesArgs& a, hipStream_t st) {
-  auto kern = k_lines<PriceT, kLds, LPL, kLife, kSnap>;
+  auto kern = k_lines<PriceT, kLds, LPL, kLife, kSnap, kPriceGlobal>;
   {
     int rc = set_dyn_lds(ctx, kern, pl.lds_bytes);
     if (rc) return rc;
@@ -410,7 +423,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.order_total = d_tot; a.prod_slab = ctx->d_prod_slab.p; a.prod_carry = ctx->d_prod_carry.p;
     a.rec_id = ctx->d_rec_id.p; a.rec_sum = ctx->d_rec_sum.p; a.status = ctx->d_status;
     a.line_price = reinterpret_cast<const long long*>(d_line_price);
-    a.price_in_lds = xpose_prices ? 0 : 1;
+    a.price_in_lds = lp.price_lds ? 1 : 0;
     a.only_if_unsorted = 0;
     a.totals_only = 0;
     a.fill_edges = fused ? 1 : 0;
@@ -420,7 +433,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
     if (any_order) {
       HIPCHK(ctx, hipMemsetAsync(d_tot, 0, (size_t)n_orders * 8, st));
-      const size_t tables = lp.lds_tables ? (size_t)ctx->p_pad * (lp.price32 ? 8 : 12) : 0;
+      const size_t tables = !lp.lds_tables ? 0 : (size_t)ctx->p_pad * (!lp.price_lds ? 4 : lp.price32 ? 8 : 12);
       if (life_lines) {
         if (!lp.lds_tables) rc = launch_lines_any<int64_t, false, true>(ctx, lp, tables, a, st);
         else if (lp.price32) rc = launch_lines_any<int32_t, true, true>(ctx, lp, tables, a, st);
@@ -435,10 +448,12 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       if (d_line_price) rc = lp.lds_tables ? launch_lines<int64_t, true, 4, true, true>(ctx, lp, a, st)
                                            : launch_lines<int64_t, false, 4, true, true>(ctx, lp, a, st);
       else if (!lp.lds_tables) rc = launch_lines<int64_t, false, 4, true>(ctx, lp, a, st);
+      else if (!lp.price_lds) rc = launch_lines<int64_t, true, 4, true, false, true>(ctx, lp, a, st);
       else if (lp.price32) rc = launch_lines<int32_t, true, 4, true>(ctx, lp, a, st);
       else rc = launch_lines<int64_t, true, 4, true>(ctx, lp, a, st);
     }
     else if (!lp.lds_tables) rc = launch_lines<int64_t, false, 4>(ctx, lp, a, st);
+    else if (!lp.price_lds) rc = launch_lines<int64_t, true, 4, false, false, true>(ctx, lp, a, st);
     else if (lp.price32 && lp.lpl == 8) rc = launch_lines<int32_t, true, 8>(ctx, lp, a, st);
     else if (lp.price32) rc = launch_lines<int32_t, true, 4>(ctx, lp, a, st);
     else rc = launch_lines<int64_t, true, 4>(ctx, lp, a, st);
@@ -470,10 +485,10 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       if (ap.lpl != 4) { const int keep = ctx->k1_lpl; ctx->k1_lpl = 4; plan_lines(ctx, n_lines, &ap, false); ctx->k1_lpl = keep; }
       LinesArgs b = a;
       b.n_tiles = ap.n_tiles; b.tiles_per_wave = ap.tiles_per_wave; b.tile_lines = ap.tile_lines;
-      b.price_in_lds = 1; b.only_if_unsorted = 1; b.totals_only = 1;
+      b.price_in_lds = ap.price_lds ? 1 : 0; b.only_if_unsorted = 1; b.totals_only = 1;
       hipLaunchKernelGGL(k_zero_if_unsorted, dim3(ctx->n_cu * 4), dim3(256), 0, st, d_tot, n_orders, ctx->d_status);
       HIPCHK(ctx, hipGetLastError());
-      const size_t tables = ap.lds_tables ? (size_t)ctx->p_pad * (ap.price32 ? 8 : 12) : 0;
+      const size_t tables = !ap.lds_tables ? 0 : (size_t)ctx->p_pad * (!ap.price_lds ? 4 : ap.price32 ? 8 : 12);
       if (life_lines) {
         if (!ap.lds_tables) rc = launch_lines_any<int64_t, false, true>(ctx, ap, tables, b, st);
         else if (ap.price32) rc = launch_lines_any<int32_t, true, true>(ctx, ap, tables, b, st);

@@ -61,7 +61,7 @@ struct LinesArgs {
   uint32_t* status;
   // order lifecycle (kLife kernels only; each may be null)
   const long long* line_price;        // [n_lines] price at the time of sale, instead of the table
-  int32_t price_in_lds;               // 0: no price table in LDS (line prices make it unnecessary)
+  int32_t price_in_lds;               // 0: no price table in LDS (line prices make it unnecessary, or it does not fit)
   // k_lines_any as the fallback of the grouped kernel: run only if the grouped pass found the ids
   // unsorted, and redo the order totals only (stock deltas do not depend on the row order)
   int32_t only_if_unsorted;
@@ -209,7 +209,7 @@ __device__ __forceinline__ void stage_flush(const LinesArgs& a, long long* s_sta
 // snap[i] is the line's own price; otherwise qh is qs and the table price is used.  (snap is an array
 // reference, not a pointer: indexed through a pointer that may be null the prices end up in scratch
 // memory, and waiting for a scratch load also waits for the next tile's loads, which were issued first.)
-template <typename PriceT, bool kLdsTables, int LPL, bool kLife = false>
+template <typename PriceT, bool kLdsTables, int LPL, bool kLife = false, bool kPriceGlobal = false>
 __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_price, uint32_t* s_hist,
                                            long long* s_stage, const int (&ids)[LPL], const int (&prs)[LPL],
                                            const int (&qs)[LPL], int lane, uint32_t lt_lo, uint32_t lt_hi,
@@ -234,12 +234,19 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
     if (kLife && snapped) {
 #pragma unroll
       for (int i = 0; i < LPL; ++i) v[i] = (pi[i] < P ? snap[i] : 0ll) * (long long)qs[i];
-    } else {
+    } else if (!kPriceGlobal) {
       PriceT price[LPL];
 #pragma unroll
       for (int i = 0; i < LPL; ++i) price[i] = s_price[pi[i]];
 #pragma unroll
       for (int i = 0; i < LPL; ++i) v[i] = (long long)price[i] * (long long)qs[i];
+    } else {
+      // the price table did not fit beside the histogram: gathered from global memory (it stays in L2)
+      long long price[LPL];
+#pragma unroll
+      for (int i = 0; i < LPL; ++i) price[i] = a.price[pi[i]];
+#pragma unroll
+      for (int i = 0; i < LPL; ++i) v[i] = price[i] * (long long)qs[i];
     }
   } else {
 #pragma unroll
@@ -410,7 +417,10 @@ __device__ __forceinline__ void load_prices(const long long* p, long long (&out)
 // the pointer, so that the loads of that column and their uses are on one path for the compiler: with a
 // run-time test it has to assume that a load into the same registers may still be pending from a path
 // that never happens, and waits for it (and for everything requested before it) in the middle of the loop.
-template <typename PriceT, bool kLdsTables, int LPL, bool kLife = false, bool kSnap = false>
+// kPriceGlobal: only the stock-delta histogram is in LDS, the prices are gathered from global memory (a
+// product table too large for both; a template parameter because a run-time test in the tile routine
+// costs the common case 8 %).
+template <typename PriceT, bool kLdsTables, int LPL, bool kLife = false, bool kSnap = false, bool kPriceGlobal = false>
 __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
   static_assert(!kLife || LPL == 4, "lifecycle columns are read four lines per lane");
   static_assert(kLife || !kSnap, "line prices are a lifecycle column");
@@ -424,7 +434,7 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
   // of stage_cap slots followed by 64 scratch slots.
   // With line prices (lifecycle) the price table is left out and every wave gets a 2 KB slice, after
   // the staging slices, through which it re-orders the coalesced price loads.
-  const bool price_lds = !kLife || a.price_in_lds != 0;
+  constexpr bool price_lds = !kSnap && !kPriceGlobal;
   const size_t price_bytes = (kLdsTables && price_lds) ? (size_t)a.p_pad * sizeof(PriceT) : 0;
   const size_t tables = kLdsTables ? price_bytes + (size_t)a.p_pad * sizeof(uint32_t) : 0;
   PriceT* s_price = reinterpret_cast<PriceT*>(smem);
@@ -496,10 +506,10 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
           for (int i = 0; i < LPL; ++i) asm volatile("" : "+v"(stt[i]));   // the states are first looked at here
           int qh[LPL];
           live_quantities<LPL>(qs, stt, qh);
-          lines_tile<PriceT, kLdsTables, LPL, true>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qh,
+          lines_tile<PriceT, kLdsTables, LPL, true, kPriceGlobal>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qh,
                                                     sn, snapped);
         } else {
-          lines_tile<PriceT, kLdsTables, LPL>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs, sn, false);
+          lines_tile<PriceT, kLdsTables, LPL, false, kPriceGlobal>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs, sn, false);
         }
         if (bursts && --until_burst == 0) {
           until_burst = a.burst;
@@ -530,11 +540,11 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
         uint32_t stt[LPL];
         load_states<LPL>(a, ids, stt);
         live_quantities<LPL>(qs, stt, qh);
-        lines_tile<PriceT, kLdsTables, LPL, true>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qh,
+        lines_tile<PriceT, kLdsTables, LPL, true, kPriceGlobal>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qh,
                                                   sn, snapped);
       } else {
         const long long none[LPL] = {};
-        lines_tile<PriceT, kLdsTables, LPL>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs, none, false);
+        lines_tile<PriceT, kLdsTables, LPL, false, kPriceGlobal>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs, none, false);
       }
     }
     // orders closed since the last flush (everything below the order that is still open)
@@ -582,7 +592,7 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
   if (a.only_if_unsorted && !(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStUnsorted))
     return;                                             // uniform: the whole grid leaves
   const bool hist = !a.totals_only;
-  const bool price_lds = !kLife || a.price_in_lds != 0;
+  const bool price_lds = a.price_in_lds != 0;
   PriceT* s_price = reinterpret_cast<PriceT*>(smem);
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + (price_lds ? (size_t)a.p_pad * sizeof(PriceT) : 0));
   if (kLdsTables) {
@@ -640,7 +650,7 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
     for (int i = 0; i < LPL; ++i) {
       const long long own = pi[i] < P ? sn[i] : 0ll;        // the line's own price (lifecycle)
       if (kLdsTables) {
-        v[i] = (snapped ? own : (long long)s_price[price_lds ? pi[i] : 0]) * (long long)qs[i];
+        v[i] = (snapped ? own : price_lds ? (long long)s_price[pi[i]] : a.price[pi[i]]) * (long long)qs[i];
         if (hist) {
           __hip_atomic_fetch_add(&s_hist[pi[i]], (uint32_t)qh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           qmax = max(qmax, (uint32_t)qh[i]);

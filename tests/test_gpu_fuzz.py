@@ -121,7 +121,7 @@ def test_random_medium_inputs_with_poisoned_outputs(oracle, fuse):
         hi = n_orders - int(rng.integers(0, max(1, n_orders // 3)))
         hi = max(hi, lo + 1)
         oid = (np.sort(rng.integers(lo, hi, size=n_lines)) + base).astype(np.int32)
-        p = int(rng.choice([3, 1000, 10_000, 70_000]))
+        p = int(rng.choice([3, 1000, 10_000, 20_000, 28_000, 70_000]))       # both tables in LDS / the histogram alone / neither
         c = int(rng.choice([1, 500, 100_000, 600_000]))
         pidx = rng.integers(-1, p + 1, size=n_lines).astype(np.int32)
         qty = (np.ones(n_lines) if rng.random() < 0.5 else rng.integers(-3, 100_000, size=n_lines)).astype(np.int32)

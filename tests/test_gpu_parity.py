@@ -279,6 +279,34 @@ def test_page_locked_columns_and_results(motor, oracle):
     assert empty.size == 0
 
 
+@pytest.mark.parametrize("p", [14_000, 20_000, 29_000, 31_000])
+@pytest.mark.parametrize("order", [False, True, "auto"])
+def test_product_tables_around_the_lds_limits(motor, oracle, p, order):
+    """Prices and histogram in LDS, the histogram alone (prices gathered from global memory), neither."""
+    rng = np.random.default_rng(p)
+    m, c = 60_000, 5_000
+    lens = rng.integers(0, 9, m)
+    oid = np.repeat(np.arange(m, dtype=np.int32) + 5, lens)
+    n = oid.size
+    pidx = rng.integers(-1, p + 1, n).astype(np.int32)
+    qty = rng.integers(0, 5, n).astype(np.int32)
+    cust = rng.integers(0, c, m).astype(np.int32)
+    price = rng.integers(1, 3_000_000_000, p).astype(np.int64)          # some beyond int32
+    if order is not False:
+        perm = rng.permutation(n)
+        oid, pidx, qty = oid[perm], pidx[perm], qty[perm]
+    motor.orden_lineas(order)
+    try:
+        motor.cargar_productos(price)
+        got = motor.agregar(oid, pidx, qty, cust, 5, c)
+    finally:
+        motor.orden_lineas(False)
+    etot, epq, ect, flags = oracle.aggregate(oid, pidx, qty, cust, 5, c, price)
+    assert flags & ~2 == 0
+    for g, e in zip(got, (etot, epq, ect)):
+        np.testing.assert_array_equal(g, e)
+
+
 # ---- device-resident path, generator parity, properties at full size ------------------------------
 
 def _device_run(motor, ds):
