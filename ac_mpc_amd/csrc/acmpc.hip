@@ -298,6 +298,38 @@ void plan_customers(const acmpc_ctx* ctx, int64_t n_orders, int32_t n_customers,
   p->tiles_per_stream = std::max<int64_t>(1, (p->n_tiles + p->n_streams - 1) / p->n_streams);
 }
 
+// The stock-delta pass of its own (k_stock), for product tables whose histogram does not fit LDS.
+struct StockPlan {
+  bool use;
+  int n_ranges, span, n_streams, blocks;
+  size_t lds_bytes;
+  int64_t n_tiles, tiles_per_stream;
+  uint32_t q_small;
+};
+
+void plan_stock(const acmpc_ctx* ctx, int64_t n_lines, StockPlan* p) {
+  const int64_t max_span = (((int64_t)kMaxLds - kLdsReserve) / 4) & ~(int64_t)3;
+  const int64_t r64 = std::max<int64_t>(1, (ctx->n_products + max_span - 1) / max_span);
+  p->use = !ctx->force_global_tables && n_lines > 0 && r64 <= 64;
+  if (!p->use) return;
+  const int slots = std::max(1, ctx->n_cu / 8);
+  p->n_ranges = (int)r64;
+  p->span = (int)((ctx->n_products + r64 - 1) / r64);
+  p->span = (p->span + 3) & ~3;
+  p->lds_bytes = (size_t)p->span * 4;
+  p->n_tiles = (n_lines + kTile - 1) / kTile;
+  int groups = std::max(1, slots / p->n_ranges);
+  // small inputs: every stream keeps a few tiles per wave; large tables: at most 512 MB of slabs
+  groups = (int)std::min<int64_t>(groups, std::max<int64_t>(1, (p->n_tiles + 8 * 32 - 1) / (8 * 32)));
+  groups = (int)std::min<int64_t>(groups, std::max<int64_t>(1, ((int64_t)512 << 20) / ((int64_t)ctx->p_pad * 4 * 8)));
+  p->n_streams = 8 * groups;
+  p->blocks = p->n_streams * p->n_ranges;
+  p->tiles_per_stream = std::max<int64_t>(1, (p->n_tiles + p->n_streams - 1) / p->n_streams);
+  // a workgroup adds at most the lines of its stream, each below q_small, into a 32-bit cell
+  const uint64_t lim = 0xffffffffull / std::max<uint64_t>(1, (uint64_t)p->tiles_per_stream * kTile);
+  p->q_small = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(65536, lim));
+}
+
 int clear_carries(acmpc_ctx* ctx, hipStream_t st) {
   if (ctx->d_prod_carry.p)
     HIPCHK(ctx, hipMemsetAsync(ctx->d_prod_carry.p, 0, ctx->d_prod_carry.cap * 8, st));
@@ -405,6 +437,12 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     if ((rc = ensure(ctx, ctx->d_rec_id, (size_t)2 * kMaxWavesTotal))) return rc;
     if ((rc = ensure(ctx, ctx->d_rec_sum, (size_t)2 * kMaxWavesTotal))) return rc;
     if (lp.lds_tables && (rc = ensure(ctx, ctx->d_prod_slab, (size_t)lp.blocks * ctx->p_pad))) return rc;
+    // neither product table fits LDS: the line pass gathers prices from global memory and leaves the
+    // stock deltas to a pass of their own (rather than one global atomic per line)
+    StockPlan sp;
+    sp.use = false;
+    if (!lp.lds_tables) plan_stock(ctx, n_lines, &sp);
+    if (sp.use && (rc = ensure(ctx, ctx->d_prod_slab, (size_t)sp.n_streams * ctx->p_pad))) return rc;
 
     LinesArgs a;
     a.order_id = d_order_id; a.product_idx = d_product_idx; a.qty = d_qty;
@@ -429,6 +467,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.fill_edges = fused ? 1 : 0;
     a.burst = life_lines ? 0 : ctx->k1_burst;     // (measured: no gain with the lifecycle columns)
     a.order_state = d_state;
+    a.no_hist = sp.use ? 1 : 0;
 
     ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
     if (any_order) {
@@ -458,22 +497,33 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     else if (lp.price32) rc = launch_lines<int32_t, true, 4>(ctx, lp, a, st);
     else rc = launch_lines<int64_t, true, 4>(ctx, lp, a, st);
     if (rc) return rc;
+    if (sp.use) {
+      StockArgs k;
+      k.order_id = d_order_id; k.product_idx = d_product_idx; k.qty = d_qty;
+      k.n_lines = n_lines; k.n_tiles = sp.n_tiles; k.tiles_per_stream = sp.tiles_per_stream;
+      k.n_products = P; k.p_pad = ctx->p_pad; k.span = sp.span; k.n_ranges = sp.n_ranges; k.n_streams = sp.n_streams;
+      k.q_small = sp.q_small; k.prod_slab = ctx->d_prod_slab.p; k.prod_carry = ctx->d_prod_carry.p;
+      k.base = base; k.n_orders = (int32_t)n_orders; k.order_state = d_state;
+      if ((rc = set_dyn_lds(ctx, k_stock, sp.lds_bytes))) return rc;
+      hipLaunchKernelGGL(k_stock, dim3(sp.blocks), dim3(1024), sp.lds_bytes, st, k);
+      HIPCHK(ctx, hipGetLastError());
+    }
     if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
 
     f.rec_id = ctx->d_rec_id.p; f.rec_sum = ctx->d_rec_sum.p; f.n_rec = 2 * lp.n_active_waves;
     f.base = base; f.n_orders = (int32_t)n_orders; f.order_total = d_tot; f.status = ctx->d_status;
-    f.prod_slab = ctx->d_prod_slab.p; f.n_slabs = lp.blocks; f.p_pad = ctx->p_pad; f.n_products = P;
-    f.merge_products = lp.lds_tables ? 1 : 0;
+    f.prod_slab = ctx->d_prod_slab.p; f.n_slabs = sp.use ? sp.n_streams : lp.blocks; f.p_pad = ctx->p_pad; f.n_products = P;
+    f.merge_products = (lp.lds_tables || sp.use) ? 1 : 0;
     f.fix_orders = any_order ? 0 : 1;
     f.prod_carry = ctx->d_prod_carry.p; f.product_qty = d_pq;
     f.ablate = ctx->ablate_fix;
     if (!fused) {
       if ((rc = set_dyn_lds(ctx, k_fixup, fix_lds))) return rc;
-      const int fix_blocks = 1 + (lp.lds_tables ? (P + kMergeProducts - 1) / kMergeProducts : 0);
+      const int fix_blocks = 1 + (f.merge_products ? (P + kMergeProducts - 1) / kMergeProducts : 0);
       hipLaunchKernelGGL(k_fixup, dim3(fix_blocks), dim3(kFixThreads), fix_lds, st, f);
       HIPCHK(ctx, hipGetLastError());
     }
-    if (!lp.lds_tables) {
+    if (!f.merge_products) {
       hipLaunchKernelGGL(k_move_clear, dim3((P + 255) / 256), dim3(256), 0, st, ctx->d_prod_carry.p, d_pq, P);
       HIPCHK(ctx, hipGetLastError());
     }

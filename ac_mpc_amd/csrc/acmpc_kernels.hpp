@@ -75,6 +75,7 @@ struct LinesArgs {
   // bursts than trickling in between the reads.  Only in workgroups whose waves all have full runs.
   int32_t burst;
   const unsigned char* order_state;   // [M] bit 0: the order counts towards stock and customer sums
+  int32_t no_hist;                    // global-table kernels: leave the stock deltas to k_stock
 };
 
 // Lifecycle: quantities that reach the stock delta (0 for lines of orders that do not count).
@@ -253,7 +254,7 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
     for (int i = 0; i < LPL; ++i) {
       const long long pr = (kLife && snapped) ? (pi[i] < P ? snap[i] : 0ll) : a.price[pi[i]];
       v[i] = pr * (long long)qs[i];
-      if (pi[i] < P) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qh[i]);
+      if (pi[i] < P && !a.no_hist) atomicAdd(&a.prod_carry[pi[i]], (unsigned long long)(long long)qh[i]);
     }
   }
 
@@ -591,7 +592,7 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
   const uint32_t P = (uint32_t)a.n_products;
   if (a.only_if_unsorted && !(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStUnsorted))
     return;                                             // uniform: the whole grid leaves
-  const bool hist = !a.totals_only;
+  const bool hist = !a.totals_only && !(a.no_hist && !kLdsTables);
   const bool price_lds = a.price_in_lds != 0;
   PriceT* s_price = reinterpret_cast<PriceT*>(smem);
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + (price_lds ? (size_t)a.p_pad * sizeof(PriceT) : 0));
@@ -926,6 +927,93 @@ __device__ __forceinline__ void fixup_records(const FixArgs& a, unsigned char* s
     block_fill_zero(a.order_total, (long long)last_id + 1 - a.base, a.n_orders, a.n_orders);
   }
   if (st) atomicOr(a.status, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_stock — the stock deltas on their own, for product tables whose 32-bit histogram does not fit one
+// workgroup's LDS.  Built like the customer pass: the products are cut into R ranges, the lines into
+// streams; workgroup (stream s, range r) reads the stream's product_idx / qty columns (the R siblings of
+// a stream share them through their XCD's L2), adds the quantities of its range into an LDS histogram
+// and writes it as slice r of slab s.  merge_product_group sums the slabs.  The alternative, one 64-bit
+// global atomic per line, is bound by the 23 G/s scattered-atomic rate of the part.
+// ---------------------------------------------------------------------------------------------
+struct StockArgs {
+  const int32_t* order_id;            // only read when order_state is not null
+  const int32_t* product_idx;
+  const int32_t* qty;
+  int64_t n_lines;
+  int64_t n_tiles;                    // ceil(N / 256)
+  int64_t tiles_per_stream;
+  int32_t n_products;
+  int32_t p_pad;                      // slab row pitch
+  int32_t span;                       // products per range (a multiple of 4)
+  int32_t n_ranges;
+  int32_t n_streams;
+  uint32_t q_small;                   // quantities in [0, q_small) go to the LDS histogram
+  uint32_t* prod_slab;                // [n_streams][p_pad]
+  unsigned long long* prod_carry;     // [P] 64-bit cells for every other quantity
+  int32_t base, n_orders;
+  const unsigned char* order_state;   // [M] or null
+};
+
+__global__ void __launch_bounds__(1024) k_stock(StockArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* s_tab = reinterpret_cast<uint32_t*>(smem);
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const int waves_per_block = (int)(blockDim.x >> 6);
+  const int x = (int)blockIdx.x & 7, jslot = (int)blockIdx.x >> 3;
+  const int r = jslot % a.n_ranges;
+  const int s = x + 8 * (jslot / a.n_ranges);
+  const int lo = r * a.span;
+  int len = a.n_products - lo;
+  if (len > a.span) len = a.span;
+  if (len < 0) len = 0;
+  for (int i = (int)threadIdx.x * 4; i < a.span; i += (int)blockDim.x * 4)
+    *reinterpret_cast<uint4*>(s_tab + i) = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  const long long t0 = (long long)s * a.tiles_per_stream;
+  long long t1 = t0 + a.tiles_per_stream;
+  if (t1 > a.n_tiles) t1 = a.n_tiles;
+  const uint32_t top = (uint32_t)a.n_orders - 1u;
+  for (long long t = t0 + wave; t < t1; t += waves_per_block) {
+    const long long l0 = t * kTile + (long long)lane * 4;
+    int pr[4], q[4], id[4] = {0, 0, 0, 0};
+    if (l0 + 4 <= a.n_lines) {
+      load_lines<4>(a.product_idx + l0, pr);
+      load_lines<4>(a.qty + l0, q);
+      if (a.order_state) load_lines<4>(a.order_id + l0, id);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool in = l0 + i < a.n_lines;
+        pr[i] = in ? a.product_idx[l0 + i] : -1;
+        q[i] = in ? a.qty[l0 + i] : 0;
+        id[i] = (in && a.order_state) ? a.order_id[l0 + i] : a.base;
+      }
+    }
+    if (a.order_state) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (!(a.order_state[min((uint32_t)id[i] - (uint32_t)a.base, top)] & 1)) q[i] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t off = (uint32_t)pr[i] - (uint32_t)lo;       // a product outside [0, P) is in no range
+      if (off < (uint32_t)len) {
+        if ((uint32_t)q[i] < a.q_small)
+          __hip_atomic_fetch_add(s_tab + off, (uint32_t)q[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else
+          atomicAdd(&a.prod_carry[pr[i]], (unsigned long long)(long long)q[i]);
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t* slab = a.prod_slab + (size_t)s * a.p_pad + lo;       // lo and p_pad are multiples of 4
+  const int len4 = len & ~3;
+  for (int i = (int)threadIdx.x * 4; i < len4; i += (int)blockDim.x * 4)
+    *reinterpret_cast<uint4*>(slab + i) = *reinterpret_cast<const uint4*>(s_tab + i);
+  for (int i = len4 + (int)threadIdx.x; i < len; i += (int)blockDim.x) slab[i] = s_tab[i];
 }
 
 // ---------------------------------------------------------------------------------------------
