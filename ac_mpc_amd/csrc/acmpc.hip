@@ -195,7 +195,8 @@ int set_dyn_lds(acmpc_ctx* ctx, K kernel, size_t bytes) {
 
 struct LinesPlan {
   bool lds_tables;
-  bool price_lds;          // the price table is in LDS too (not with line prices, not when only the histogram fits)
+  bool price_lds;          // the price table is in LDS (not with line prices, not when only the histogram fits)
+  bool hist_lds;           // the stock-delta histogram is in LDS (not when only the price table fits)
   bool price32;
   size_t lds_bytes;
   int threads, blocks, waves_per_block;
@@ -213,6 +214,7 @@ int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p, bool line_pr
   const size_t need32 = (size_t)ctx->p_pad * 8, need64 = (size_t)ctx->p_pad * 12;
   p->price32 = ctx->price_fits32;
   p->price_lds = !line_prices;
+  p->hist_lds = true;
   p->lds_bytes = line_prices ? (size_t)ctx->p_pad * 4 : p->price32 ? need32 : need64;
   p->threads = ctx->k1_threads;
   p->waves_per_block = p->threads / kWave;
@@ -222,19 +224,32 @@ int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p, bool line_pr
   auto stage_bytes = [&](uint32_t cap) {
     return (size_t)p->waves_per_block * ((cap + kWave) * 8 + (line_prices ? 2048 : 0));
   };
-  p->lds_tables = !ctx->force_global_tables && p->lds_bytes + stage_bytes(kTile) + kLdsReserve <= (size_t)kMaxLds;
-  if (!p->lds_tables && !ctx->force_global_tables && !line_prices &&
-      (size_t)ctx->p_pad * 4 + stage_bytes(kTile) + kLdsReserve <= (size_t)kMaxLds) {
-    // the stock-delta histogram alone still fits: keep it in LDS (the alternative is one global atomic per
-    // line) and gather the prices from global memory, where a table of this size stays in L2
-    p->lds_tables = true;
-    p->price_lds = false;
-    p->price32 = false;
-    p->lds_bytes = (size_t)ctx->p_pad * 4;
-    p->lpl = 4;
-    p->tile_lines = kTile;
+  auto fits = [&](size_t table_bytes) { return table_bytes + stage_bytes(kTile) + kLdsReserve <= (size_t)kMaxLds; };
+  p->lds_tables = !ctx->force_global_tables && fits(p->lds_bytes);
+  if (!p->lds_tables && !ctx->force_global_tables && !line_prices) {
+    const size_t price_bytes = (size_t)ctx->p_pad * (p->price32 ? 4 : 8), hist_bytes = (size_t)ctx->p_pad * 4;
+    if (fits(price_bytes)) {
+      // Both tables do not fit, the price table alone does: keep it (a price is read for every line in the
+      // middle of the dependent work of a tile) and leave the stock deltas to k_stock.
+      p->lds_tables = true;
+      p->hist_lds = false;
+      p->lds_bytes = price_bytes;
+      p->lpl = 4;
+      p->tile_lines = kTile;
+    } else if (fits(hist_bytes)) {
+      // 64-bit prices: only the histogram fits.  It stays in LDS and the prices are gathered from global
+      // memory, where a table of this size stays in L2.
+      p->lds_tables = true;
+      p->price_lds = false;
+      p->price32 = false;
+      p->lds_bytes = hist_bytes;
+      p->lpl = 4;
+      p->tile_lines = kTile;
+    }
   }
-  if (!p->lds_tables) { p->lds_bytes = 0; p->price32 = false; p->price_lds = false; p->lpl = 4; p->tile_lines = kTile; }
+  if (!p->lds_tables) {
+    p->lds_bytes = 0; p->price32 = false; p->price_lds = false; p->hist_lds = false; p->lpl = 4; p->tile_lines = kTile;
+  }
   p->stage_cap = 512;
   while (p->stage_cap > (uint32_t)kTile && p->lds_bytes + stage_bytes(p->stage_cap) + kLdsReserve > (size_t)kMaxLds)
     p->stage_cap >>= 1;
@@ -339,9 +354,10 @@ int clear_carries(acmpc_ctx* ctx, hipStream_t st) {
   return ACMPC_OK;
 }
 
-template <typename PriceT, bool kLds, int LPL, bool kLife = false, bool kSnap = false, bool kPriceGlobal = false>
+template <typename PriceT, bool kLds, int LPL, bool kLife = false, bool kSnap = false, bool kPriceGlobal = false,
+          bool kNoHist = false>
 int launch_lines(acmpc_ctx* ctx, const LinesPlan& pl, const LinesArgs& a, hipStream_t st) {
-  auto kern = k_lines<PriceT, kLds, LPL, kLife, kSnap, kPriceGlobal>;
+  auto kern = k_lines<PriceT, kLds, LPL, kLife, kSnap, kPriceGlobal, kNoHist>;
   {
     int rc = set_dyn_lds(ctx, kern, pl.lds_bytes);
     if (rc) return rc;
@@ -419,7 +435,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
   // shorter and the four-launch sequence is quicker.  ACMPC_FUSE=2 forces the fused path for tests.)
   const bool fused = ctx->fuse && ctx->line_order == ACMPC_ORDER_GROUPED && !life && n_lines > 0 &&
                      (n_orders >= 4000000 || (ctx->fuse == 2 && n_orders > 0)) &&
-                     lp.lds_tables && cp.lds_tables && cp.threads == kFixThreads;
+                     lp.lds_tables && lp.hist_lds && cp.lds_tables && cp.threads == kFixThreads;
   FixArgs f;
   memset(&f, 0, sizeof(f));
   const size_t fix_lds = (size_t)kFixThreads * kFixStrip * 12;
@@ -436,12 +452,12 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     if ((rc = ensure(ctx, ctx->d_prod_carry, (size_t)ctx->p_pad, true))) return rc;
     if ((rc = ensure(ctx, ctx->d_rec_id, (size_t)2 * kMaxWavesTotal))) return rc;
     if ((rc = ensure(ctx, ctx->d_rec_sum, (size_t)2 * kMaxWavesTotal))) return rc;
-    if (lp.lds_tables && (rc = ensure(ctx, ctx->d_prod_slab, (size_t)lp.blocks * ctx->p_pad))) return rc;
+    if (lp.hist_lds && (rc = ensure(ctx, ctx->d_prod_slab, (size_t)lp.blocks * ctx->p_pad))) return rc;
     // neither product table fits LDS: the line pass gathers prices from global memory and leaves the
     // stock deltas to a pass of their own (rather than one global atomic per line)
     StockPlan sp;
     sp.use = false;
-    if (!lp.lds_tables) plan_stock(ctx, n_lines, &sp);
+    if (!lp.hist_lds) plan_stock(ctx, n_lines, &sp);
     if (sp.use && (rc = ensure(ctx, ctx->d_prod_slab, (size_t)sp.n_streams * ctx->p_pad))) return rc;
 
     LinesArgs a;
@@ -472,7 +488,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
     if (any_order) {
       HIPCHK(ctx, hipMemsetAsync(d_tot, 0, (size_t)n_orders * 8, st));
-      const size_t tables = !lp.lds_tables ? 0 : (size_t)ctx->p_pad * (!lp.price_lds ? 4 : lp.price32 ? 8 : 12);
+      const size_t tables = !lp.lds_tables ? 0 : (size_t)ctx->p_pad * ((lp.price_lds ? (lp.price32 ? 4 : 8) : 0) + (lp.hist_lds ? 4 : 0));
       if (life_lines) {
         if (!lp.lds_tables) rc = launch_lines_any<int64_t, false, true>(ctx, lp, tables, a, st);
         else if (lp.price32) rc = launch_lines_any<int32_t, true, true>(ctx, lp, tables, a, st);
@@ -488,11 +504,15 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
                                            : launch_lines<int64_t, false, 4, true, true>(ctx, lp, a, st);
       else if (!lp.lds_tables) rc = launch_lines<int64_t, false, 4, true>(ctx, lp, a, st);
       else if (!lp.price_lds) rc = launch_lines<int64_t, true, 4, true, false, true>(ctx, lp, a, st);
+      else if (!lp.hist_lds) rc = lp.price32 ? launch_lines<int32_t, true, 4, true, false, false, true>(ctx, lp, a, st)
+                                             : launch_lines<int64_t, true, 4, true, false, false, true>(ctx, lp, a, st);
       else if (lp.price32) rc = launch_lines<int32_t, true, 4, true>(ctx, lp, a, st);
       else rc = launch_lines<int64_t, true, 4, true>(ctx, lp, a, st);
     }
     else if (!lp.lds_tables) rc = launch_lines<int64_t, false, 4>(ctx, lp, a, st);
     else if (!lp.price_lds) rc = launch_lines<int64_t, true, 4, false, false, true>(ctx, lp, a, st);
+    else if (!lp.hist_lds) rc = lp.price32 ? launch_lines<int32_t, true, 4, false, false, false, true>(ctx, lp, a, st)
+                                           : launch_lines<int64_t, true, 4, false, false, false, true>(ctx, lp, a, st);
     else if (lp.price32 && lp.lpl == 8) rc = launch_lines<int32_t, true, 8>(ctx, lp, a, st);
     else if (lp.price32) rc = launch_lines<int32_t, true, 4>(ctx, lp, a, st);
     else rc = launch_lines<int64_t, true, 4>(ctx, lp, a, st);
@@ -513,7 +533,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     f.rec_id = ctx->d_rec_id.p; f.rec_sum = ctx->d_rec_sum.p; f.n_rec = 2 * lp.n_active_waves;
     f.base = base; f.n_orders = (int32_t)n_orders; f.order_total = d_tot; f.status = ctx->d_status;
     f.prod_slab = ctx->d_prod_slab.p; f.n_slabs = sp.use ? sp.n_streams : lp.blocks; f.p_pad = ctx->p_pad; f.n_products = P;
-    f.merge_products = (lp.lds_tables || sp.use) ? 1 : 0;
+    f.merge_products = (lp.hist_lds || sp.use) ? 1 : 0;
     f.fix_orders = any_order ? 0 : 1;
     f.prod_carry = ctx->d_prod_carry.p; f.product_qty = d_pq;
     f.ablate = ctx->ablate_fix;
@@ -538,7 +558,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       b.price_in_lds = ap.price_lds ? 1 : 0; b.only_if_unsorted = 1; b.totals_only = 1;
       hipLaunchKernelGGL(k_zero_if_unsorted, dim3(ctx->n_cu * 4), dim3(256), 0, st, d_tot, n_orders, ctx->d_status);
       HIPCHK(ctx, hipGetLastError());
-      const size_t tables = !ap.lds_tables ? 0 : (size_t)ctx->p_pad * (!ap.price_lds ? 4 : ap.price32 ? 8 : 12);
+      const size_t tables = !ap.lds_tables ? 0 : (size_t)ctx->p_pad * ((ap.price_lds ? (ap.price32 ? 4 : 8) : 0) + (ap.hist_lds ? 4 : 0));
       if (life_lines) {
         if (!ap.lds_tables) rc = launch_lines_any<int64_t, false, true>(ctx, ap, tables, b, st);
         else if (ap.price32) rc = launch_lines_any<int32_t, true, true>(ctx, ap, tables, b, st);

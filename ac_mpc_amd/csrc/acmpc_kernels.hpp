@@ -75,7 +75,7 @@ struct LinesArgs {
   // bursts than trickling in between the reads.  Only in workgroups whose waves all have full runs.
   int32_t burst;
   const unsigned char* order_state;   // [M] bit 0: the order counts towards stock and customer sums
-  int32_t no_hist;                    // global-table kernels: leave the stock deltas to k_stock
+  int32_t no_hist;                    // the stock deltas are left to k_stock (global-table kernels, k_lines_any)
 };
 
 // Lifecycle: quantities that reach the stock delta (0 for lines of orders that do not count).
@@ -210,7 +210,7 @@ __device__ __forceinline__ void stage_flush(const LinesArgs& a, long long* s_sta
 // snap[i] is the line's own price; otherwise qh is qs and the table price is used.  (snap is an array
 // reference, not a pointer: indexed through a pointer that may be null the prices end up in scratch
 // memory, and waiting for a scratch load also waits for the next tile's loads, which were issued first.)
-template <typename PriceT, bool kLdsTables, int LPL, bool kLife = false, bool kPriceGlobal = false>
+template <typename PriceT, bool kLdsTables, int LPL, bool kLife = false, bool kPriceGlobal = false, bool kNoHist = false>
 __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_price, uint32_t* s_hist,
                                            long long* s_stage, const int (&ids)[LPL], const int (&prs)[LPL],
                                            const int (&qs)[LPL], int lane, uint32_t lt_lo, uint32_t lt_hi,
@@ -227,10 +227,12 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
     // The host sizes q_small so that a workgroup's sum of quantities below q_small cannot wrap; a
     // quantity outside [0, q_small) (never produced by the reference, which always writes 1) is
     // detected through qmax, taken back out of the histogram and sent to a 64-bit global atomic.
+    if constexpr (!kNoHist) {
 #pragma unroll
-    for (int i = 0; i < LPL; ++i) {
-      __hip_atomic_fetch_add(&s_hist[pi[i]], (uint32_t)qh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      qmax = max(qmax, (uint32_t)qh[i]);
+      for (int i = 0; i < LPL; ++i) {
+        __hip_atomic_fetch_add(&s_hist[pi[i]], (uint32_t)qh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        qmax = max(qmax, (uint32_t)qh[i]);
+      }
     }
     if (kLife && snapped) {
 #pragma unroll
@@ -329,7 +331,7 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
   // the staging buffer.  Empty the buffer, then write this tile's orders (and the ids they skip)
   // directly.
   stage_flush(a, s_stage, o, min(((uint32_t)o.id - (uint32_t)a.base) - o.buf_base, a.stage_cap), lane);
-  if (kLdsTables) {
+  if (kLdsTables && !kNoHist) {
 #pragma unroll
     for (int i = 0; i < LPL; ++i) {
       if ((uint32_t)qh[i] >= a.q_small) {
@@ -421,7 +423,10 @@ __device__ __forceinline__ void load_prices(const long long* p, long long (&out)
 // kPriceGlobal: only the stock-delta histogram is in LDS, the prices are gathered from global memory (a
 // product table too large for both; a template parameter because a run-time test in the tile routine
 // costs the common case 8 %).
-template <typename PriceT, bool kLdsTables, int LPL, bool kLife = false, bool kSnap = false, bool kPriceGlobal = false>
+// kNoHist: only the price table is in LDS (both do not fit, and reading prices from LDS matters more):
+// the stock deltas are left to k_stock.
+template <typename PriceT, bool kLdsTables, int LPL, bool kLife = false, bool kSnap = false, bool kPriceGlobal = false,
+          bool kNoHist = false>
 __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
   static_assert(!kLife || LPL == 4, "lifecycle columns are read four lines per lane");
   static_assert(kLife || !kSnap, "line prices are a lifecycle column");
@@ -437,7 +442,7 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
   // the staging slices, through which it re-orders the coalesced price loads.
   constexpr bool price_lds = !kSnap && !kPriceGlobal;
   const size_t price_bytes = (kLdsTables && price_lds) ? (size_t)a.p_pad * sizeof(PriceT) : 0;
-  const size_t tables = kLdsTables ? price_bytes + (size_t)a.p_pad * sizeof(uint32_t) : 0;
+  const size_t tables = kLdsTables ? price_bytes + (kNoHist ? 0 : (size_t)a.p_pad * sizeof(uint32_t)) : 0;
   PriceT* s_price = reinterpret_cast<PriceT*>(smem);
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + price_bytes);
   long long* s_stage = reinterpret_cast<long long*>(smem + tables) + (size_t)wave * (a.stage_cap + kWave);
@@ -447,7 +452,7 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
   if (kLdsTables) {
     for (int i = (int)threadIdx.x; i < P1; i += (int)blockDim.x) {
       if (price_lds) s_price[i] = (PriceT)a.price[i];
-      s_hist[i] = 0u;
+      if (!kNoHist) s_hist[i] = 0u;
     }
     __syncthreads();
   }
@@ -507,10 +512,10 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
           for (int i = 0; i < LPL; ++i) asm volatile("" : "+v"(stt[i]));   // the states are first looked at here
           int qh[LPL];
           live_quantities<LPL>(qs, stt, qh);
-          lines_tile<PriceT, kLdsTables, LPL, true, kPriceGlobal>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qh,
+          lines_tile<PriceT, kLdsTables, LPL, true, kPriceGlobal, kNoHist>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qh,
                                                     sn, snapped);
         } else {
-          lines_tile<PriceT, kLdsTables, LPL, false, kPriceGlobal>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs, sn, false);
+          lines_tile<PriceT, kLdsTables, LPL, false, kPriceGlobal, kNoHist>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs, sn, false);
         }
         if (bursts && --until_burst == 0) {
           until_burst = a.burst;
@@ -541,11 +546,11 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
         uint32_t stt[LPL];
         load_states<LPL>(a, ids, stt);
         live_quantities<LPL>(qs, stt, qh);
-        lines_tile<PriceT, kLdsTables, LPL, true, kPriceGlobal>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qh,
+        lines_tile<PriceT, kLdsTables, LPL, true, kPriceGlobal, kNoHist>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qh,
                                                   sn, snapped);
       } else {
         const long long none[LPL] = {};
-        lines_tile<PriceT, kLdsTables, LPL, false, kPriceGlobal>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs, none, false);
+        lines_tile<PriceT, kLdsTables, LPL, false, kPriceGlobal, kNoHist>(a, s_price, s_hist, s_stage, ids, prs, qs, lane, lt_lo, lt_hi, o, qs, none, false);
       }
     }
     // orders closed since the last flush (everything below the order that is still open)
@@ -568,7 +573,7 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
     if (o.st) atomicOr(a.status, o.st);
   }
 
-  if (kLdsTables) {
+  if (kLdsTables && !kNoHist) {
     __syncthreads();
     uint32_t* slab = a.prod_slab + (size_t)blockIdx.x * a.p_pad;
     for (int i = (int)threadIdx.x; i < a.n_products; i += (int)blockDim.x) slab[i] = s_hist[i];
@@ -592,14 +597,14 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
   const uint32_t P = (uint32_t)a.n_products;
   if (a.only_if_unsorted && !(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStUnsorted))
     return;                                             // uniform: the whole grid leaves
-  const bool hist = !a.totals_only && !(a.no_hist && !kLdsTables);
+  const bool hist = !a.totals_only && !a.no_hist;        // no_hist: k_stock does the stock deltas
   const bool price_lds = a.price_in_lds != 0;
   PriceT* s_price = reinterpret_cast<PriceT*>(smem);
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + (price_lds ? (size_t)a.p_pad * sizeof(PriceT) : 0));
   if (kLdsTables) {
     for (int i = (int)threadIdx.x; i < (int)P + 1; i += (int)blockDim.x) {
       if (price_lds) s_price[i] = (PriceT)a.price[i];
-      s_hist[i] = 0u;
+      if (hist) s_hist[i] = 0u;                          // (without it the histogram has no LDS of its own)
     }
     __syncthreads();
   }
