@@ -1,5 +1,9 @@
+"""Developer tool: does the library initialise whatever the order in which it and torch first touch the
+GPU?  usage: probe_load.py mine | torch_first | mine_first | load_then_torch_then_init"""
 import sys, ctypes as C, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) < 2:
+    raise SystemExit(__doc__)
 mode = sys.argv[1]
 def mine():
     from ac_mpc_amd import _lib
