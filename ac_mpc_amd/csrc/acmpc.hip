@@ -393,7 +393,10 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     if (!aligned16(d_line_price) || !aligned16(d_state) || !aligned16(d_desc))
       return fail(ctx, ACMPC_E_ALIGN, "lifecycle columns must be 16-byte aligned");
   }
-  const bool life_lines = d_line_price || d_state;
+  // In the grouped mode the discounts are taken off where the totals are stored (k_lines, k_fixup); the
+  // any-order kernels add partial sums with atomics, so there k_order_adjust goes over the finished totals.
+  const bool desc_in_lines = d_desc && ctx->line_order == ACMPC_ORDER_GROUPED && n_lines > 0;
+  const bool life_lines = d_line_price || d_state || desc_in_lines;
   if (ctx->n_products <= 0) return fail(ctx, ACMPC_E_STATE, "acmpc_set_products has not been called");
   if (n_lines < 0 || n_orders < 0 || n_customers <= 0)
     return fail(ctx, ACMPC_E_INVALID, "negative size or n_customers <= 0");
@@ -481,7 +484,9 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.only_if_unsorted = 0;
     a.totals_only = 0;
     a.fill_edges = fused ? 1 : 0;
-    a.burst = life_lines ? 0 : ctx->k1_burst;     // (measured: no gain with the lifecycle columns)
+    a.burst = (d_line_price || d_state) ? 0 : ctx->k1_burst;     // (measured: no gain with those columns)
+    a.order_descuento = desc_in_lines ? d_desc : nullptr;
+    a.descuento_mode = d_desc ? life->descuento_mode : 0;
     a.order_state = d_state;
     a.no_hist = sp.use ? 1 : 0;
 
@@ -537,6 +542,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     f.fix_orders = any_order ? 0 : 1;
     f.prod_carry = ctx->d_prod_carry.p; f.product_qty = d_pq;
     f.ablate = ctx->ablate_fix;
+    f.order_descuento = a.order_descuento; f.descuento_mode = a.descuento_mode;
     if (!fused) {
       if ((rc = set_dyn_lds(ctx, k_fixup, fix_lds))) return rc;
       const int fix_blocks = 1 + (f.merge_products ? (P + kMergeProducts - 1) / kMergeProducts : 0);
@@ -571,7 +577,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       hipLaunchKernelGGL(k_clear_unsorted, dim3(1), dim3(64), 0, st, ctx->d_status);
       HIPCHK(ctx, hipGetLastError());
     }
-    if (d_desc) {                 // totals are final after k_fixup: take the discounts off
+    if (d_desc && !desc_in_lines) {   // totals are final after k_fixup: take the discounts off
       hipLaunchKernelGGL(k_order_adjust, dim3((unsigned)((n_orders + 255) / 256)), dim3(256), 0, st, d_tot, d_desc,
                          n_orders, life->descuento_mode);
       HIPCHK(ctx, hipGetLastError());

@@ -76,6 +76,8 @@ struct LinesArgs {
   int32_t burst;
   const unsigned char* order_state;   // [M] bit 0: the order counts towards stock and customer sums
   int32_t no_hist;                    // the stock deltas are left to k_stock (global-table kernels, k_lines_any)
+  const int32_t* order_descuento;     // [M] or null (grouped kLife kernels): totals are stored net of it
+  int32_t descuento_mode;
 };
 
 // Lifecycle: quantities that reach the stock delta (0 for lines of orders that do not count).
@@ -165,12 +167,31 @@ __device__ __forceinline__ void split_add64(uint32_t* lds_lo, unsigned long long
   if (hi != 0) atomicAdd(g_hi, ((unsigned long long)hi) << 32);
 }
 
+// venta.Descuento (INT, store.sql:162; always 0 in the reference, process/confirmcompra.php:24):
+// order_total[o] -= discount.  mode 0: the column is an amount in whole currency units; mode 1: a
+// percentage of the gross total, rounded half away from zero to a cent.  Wrapping 64-bit arithmetic.
+__device__ __forceinline__ long long descuento_cents(long long gross, int d, int mode) {
+  if (mode == 0) return 100ll * (long long)d;
+  const long long q = gross / 100ll, r = gross - q * 100ll;       // truncating: r has the sign of gross
+  const long long x = r * (long long)d;                           // |x| < 100 * 2^31
+  const long long part = x >= 0 ? (x + 50ll) / 100ll : -((-x + 50ll) / 100ll);
+  return (long long)((unsigned long long)q * (unsigned long long)(long long)d) + part;
+}
+
+// The total that is stored for order index idx: the gross total less its discount when the kernel has
+// been given the Descuento column (grouped lifecycle kernels; otherwise k_order_adjust does it afterwards).
+__device__ __forceinline__ long long net_total(long long gross, uint32_t idx, const int32_t* descuento, int mode) {
+  if (!descuento) return gross;
+  return (long long)((unsigned long long)gross - (unsigned long long)descuento_cents(gross, descuento[idx], mode));
+}
+
 // Zero order_total for the order ids strictly between a and b (exclusive), all 64 lanes helping.
 // (64-bit bounds: base - 1 and base + n_orders may lie outside int32.)
+template <bool kLife = false>
 __device__ __forceinline__ void wave_fill_gap(const LinesArgs& a, long long ida, long long idb, int lane) {
   for (long long k = ida + 1 + lane; k < idb; k += kWave) {
     const uint32_t idx = (uint32_t)((int)k) - (uint32_t)a.base;
-    if (idx < (uint32_t)a.n_orders) a.order_total[idx] = 0;
+    if (idx < (uint32_t)a.n_orders) a.order_total[idx] = kLife ? net_total(0, idx, a.order_descuento, a.descuento_mode) : 0;
   }
 }
 
@@ -190,12 +211,14 @@ struct WaveRun {
 // Write the finished part of the wave's staging buffer — order indices [buf_base, buf_base + n) —
 // to order_total as contiguous 8-byte stores, and leave the buffer zeroed.  Slots never written
 // belong to orders without lines and flush as 0.
+template <bool kLife = false>
 __device__ __forceinline__ void stage_flush(const LinesArgs& a, long long* s_stage, WaveRun& o, uint32_t n, int lane) {
   for (uint32_t k = (uint32_t)lane; k < n; k += kWave) {
     const long long val = s_stage[k];
     s_stage[k] = 0;
     const uint32_t idx = o.buf_base + k;
-    if (idx < (uint32_t)a.n_orders) a.order_total[idx] = val; else o.st |= kStOrderRange;
+    if (idx < (uint32_t)a.n_orders) a.order_total[idx] = kLife ? net_total(val, idx, a.order_descuento, a.descuento_mode) : val;
+    else o.st |= kStOrderRange;
   }
   o.buf_base += n;
 }
@@ -323,14 +346,14 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
     }
     o.id = new_id;
     o.sum = readlane64(run, kWave - 1);
-    if (span > a.stage_cap - a.flush_reserve) stage_flush(a, s_stage, o, span, lane);
+    if (span > a.stage_cap - a.flush_reserve) stage_flush<kLife>(a, s_stage, o, span, lane);
     return;
   }
 
   // ---- rare path: quantities outside [0, q_small), unsorted ids, or a jump in order ids wider than
   // the staging buffer.  Empty the buffer, then write this tile's orders (and the ids they skip)
   // directly.
-  stage_flush(a, s_stage, o, min(((uint32_t)o.id - (uint32_t)a.base) - o.buf_base, a.stage_cap), lane);
+  stage_flush<kLife>(a, s_stage, o, min(((uint32_t)o.id - (uint32_t)a.base) - o.buf_base, a.stage_cap), lane);
   if (kLdsTables && !kNoHist) {
 #pragma unroll
     for (int i = 0; i < LPL; ++i) {
@@ -345,7 +368,8 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
   for (int i = 0; i < LPL; ++i) {
     if (ids[i] != pid) {
       const uint32_t idx = (uint32_t)pid - (uint32_t)a.base;
-      if (idx < (uint32_t)a.n_orders) a.order_total[idx] = run; else o.st |= kStOrderRange;
+      if (idx < (uint32_t)a.n_orders) a.order_total[idx] = kLife ? net_total(run, idx, a.order_descuento, a.descuento_mode) : run;
+      else o.st |= kStOrderRange;
       if (ids[i] < pid) o.st |= kStUnsorted;
       else if ((uint32_t)ids[i] - (uint32_t)pid > 1u) gap = true;
       run = 0;
@@ -361,7 +385,7 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
 #pragma unroll
     for (int i = 0; i < LPL; ++i) {
       const int here = __builtin_amdgcn_readlane(ids[i], L);
-      wave_fill_gap(a, before, here, lane);
+      wave_fill_gap<kLife>(a, before, here, lane);
       before = here;
     }
   }
@@ -520,7 +544,7 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
         if (bursts && --until_burst == 0) {
           until_burst = a.burst;
           __syncthreads();
-          stage_flush(a, s_stage, o, min(((uint32_t)o.id - (uint32_t)a.base) - o.buf_base, a.stage_cap), lane);
+          stage_flush<kLife>(a, s_stage, o, min(((uint32_t)o.id - (uint32_t)a.base) - o.buf_base, a.stage_cap), lane);
         }
       }
     }
@@ -554,7 +578,7 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
       }
     }
     // orders closed since the last flush (everything below the order that is still open)
-    stage_flush(a, s_stage, o, min(((uint32_t)o.id - (uint32_t)a.base) - o.buf_base, a.stage_cap), lane);
+    stage_flush<kLife>(a, s_stage, o, min(((uint32_t)o.id - (uint32_t)a.base) - o.buf_base, a.stage_cap), lane);
 
     // the run's first and last order may continue in the neighbouring waves: hand both to k_fixup
     if (lane == 0) {
@@ -567,8 +591,8 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
     }
     if (a.fill_edges) {
       const long long before = t0 == 0 ? (long long)a.base - 1 : (long long)a.order_id[t0 * kTileL - 1];
-      wave_fill_gap(a, before, head_id, lane);                // behind the last order of the wave before
-      if (t1 == a.n_tiles) wave_fill_gap(a, o.id, (long long)a.base + a.n_orders, lane);
+      wave_fill_gap<kLife>(a, before, head_id, lane);                // behind the last order of the wave before
+      if (t1 == a.n_tiles) wave_fill_gap<kLife>(a, o.id, (long long)a.base + a.n_orders, lane);
     }
     if (o.st) atomicOr(a.status, o.st);
   }
@@ -762,12 +786,16 @@ struct FixArgs {
   int32_t n_customers;
   uint32_t* edge_idx;       // [n_rec] order index, or 0xffffffff
   int64_t* edge_total;      // [n_rec]
+  const int32_t* order_descuento;   // [M] or null: the totals (and the zeros of orders without lines) are stored net of it
+  int32_t descuento_mode;
 };
 
-__device__ __forceinline__ void block_fill_zero(int64_t* out, long long lo, long long hi, int n_orders) {
+// Orders without lines, indices [lo, hi): a total of zero (less the order's discount, if any).
+__device__ __forceinline__ void block_fill_zero(int64_t* out, long long lo, long long hi, int n_orders,
+                                                const int32_t* descuento = nullptr, int mode = 0) {
   if (lo < 0) lo = 0;
   if (hi > n_orders) hi = n_orders;
-  for (long long k = lo + threadIdx.x; k < hi; k += blockDim.x) out[k] = 0;
+  for (long long k = lo + threadIdx.x; k < hi; k += blockDim.x) out[k] = net_total(0, (uint32_t)k, descuento, mode);
 }
 
 // Stock-delta merge of one group of 64 products by a workgroup of `waves` waves: wave w sums slabs
@@ -894,7 +922,7 @@ __device__ __forceinline__ void fixup_records(const FixArgs& a, unsigned char* s
         const long long total = s_excl[i] + sums[k] - s_excl[s_head[i]];
         const uint32_t idx = (uint32_t)ids[k] - (uint32_t)a.base;
         if (idx >= (uint32_t)a.n_orders) st |= kStOrderRange;
-        else if (!a.deferred) a.order_total[idx] = total;
+        else if (!a.deferred) a.order_total[idx] = net_total(total, idx, a.order_descuento, a.descuento_mode);
         else {
           const long long seen = a.order_total[idx];           // what the customer pass reads for this order
           const int32_t c = a.order_customer[idx];
@@ -913,7 +941,7 @@ __device__ __forceinline__ void fixup_records(const FixArgs& a, unsigned char* s
             else {
               for (long long q = (long long)ids[k] + 1; q < (long long)next_id; ++q) {
                 const uint32_t qi = (uint32_t)((int)q) - (uint32_t)a.base;
-                if (qi < (uint32_t)a.n_orders) a.order_total[qi] = 0;
+                if (qi < (uint32_t)a.n_orders) a.order_total[qi] = net_total(0, qi, a.order_descuento, a.descuento_mode);
               }
             }
           }
@@ -925,11 +953,11 @@ __device__ __forceinline__ void fixup_records(const FixArgs& a, unsigned char* s
   const int n_gaps = min(s_gap_n, 256);
   for (int gidx = 0; gidx < n_gaps; ++gidx)
     block_fill_zero(a.order_total, (long long)s_gap_lo[gidx] + 1 - a.base, (long long)s_gap_hi[gidx] - a.base,
-                    a.n_orders);
+                    a.n_orders, a.order_descuento, a.descuento_mode);
   // orders before the first and after the last line
   if (n > 0 && !a.deferred) {
-    block_fill_zero(a.order_total, 0, (long long)first_id - a.base, a.n_orders);
-    block_fill_zero(a.order_total, (long long)last_id + 1 - a.base, a.n_orders, a.n_orders);
+    block_fill_zero(a.order_total, 0, (long long)first_id - a.base, a.n_orders, a.order_descuento, a.descuento_mode);
+    block_fill_zero(a.order_total, (long long)last_id + 1 - a.base, a.n_orders, a.n_orders, a.order_descuento, a.descuento_mode);
   }
   if (st) atomicOr(a.status, st);
 }
@@ -1269,17 +1297,6 @@ __device__ __forceinline__ void custmerge_block(const CustMergeArgs& a, int bid,
     a.customer_total[c] = (int64_t)sum;
     a.cust_carry[c] = 0ull;           // leave the workspace clean for the next call
   }
-}
-
-// venta.Descuento (INT, store.sql:162; always 0 in the reference, process/confirmcompra.php:24):
-// order_total[o] -= discount.  mode 0: the column is an amount in whole currency units; mode 1: a
-// percentage of the gross total, rounded half away from zero to a cent.  Wrapping 64-bit arithmetic.
-__device__ __forceinline__ long long descuento_cents(long long gross, int d, int mode) {
-  if (mode == 0) return 100ll * (long long)d;
-  const long long q = gross / 100ll, r = gross - q * 100ll;       // truncating: r has the sign of gross
-  const long long x = r * (long long)d;                           // |x| < 100 * 2^31
-  const long long part = x >= 0 ? (x + 50ll) / 100ll : -((-x + 50ll) / 100ll);
-  return (long long)((unsigned long long)q * (unsigned long long)(long long)d) + part;
 }
 
 __global__ void __launch_bounds__(256) k_order_adjust(int64_t* order_total, const int32_t* descuento, int64_t n_orders,
