@@ -23,7 +23,7 @@ constexpr int kMaxLds = 160 * 1024;
 constexpr int kLdsReserve = 1024;       // static LDS some kernels declare besides the tables
 // Size limits that keep the padded counts, table sizes and chunk tickets inside 32 bits.
 constexpr int32_t kMaxProducts = 1 << 28;
-constexpr int32_t kMaxCodes = 1 << 24;
+constexpr int32_t kMaxCodes = 1 << 21;       // the code dictionary takes 64 bytes per slot, two slots per code
 constexpr int32_t kMaxCustomers = 1 << 30;
 constexpr int64_t kMaxTextBytes = 1ll << 44;
 
@@ -161,14 +161,20 @@ int guarded(acmpc_ctx* ctx, const char* who, F&& body) {
   }
 }
 
+// zero_new: a newly allocated buffer starts at zero.  The fill is queued on `st`, the stream of the call
+// that will use the buffer, so that it is ordered before that call's kernels whatever kind of stream it is
+// (a fill on the null stream is not ordered against a non-blocking stream).
 template <typename T>
-int ensure(acmpc_ctx* ctx, DevBuf<T>& b, size_t n, bool zero_new = false) {
+int ensure(acmpc_ctx* ctx, DevBuf<T>& b, size_t n, bool zero_new = false, hipStream_t st = nullptr) {
   if (n == 0) n = 1;
   if (b.cap >= n) return ACMPC_OK;
   if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
   HIPCHK(ctx, hipMalloc((void**)&b.p, n * sizeof(T)));
   b.cap = n;
-  if (zero_new) HIPCHK(ctx, hipMemset(b.p, 0, n * sizeof(T)));
+  if (zero_new) {
+    HIPCHK(ctx, hipMemsetAsync(b.p, 0, n * sizeof(T), st));
+    if (!st) HIPCHK(ctx, hipStreamSynchronize(nullptr));
+  }
   return ACMPC_OK;
 }
 
@@ -452,7 +458,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     }
     if (ctx->profiling) { HIPCHK(ctx, hipEventRecord(ctx->ev[1], st)); HIPCHK(ctx, hipEventRecord(ctx->ev[2], st)); }
   } else {
-    if ((rc = ensure(ctx, ctx->d_prod_carry, (size_t)ctx->p_pad, true))) return rc;
+    if ((rc = ensure(ctx, ctx->d_prod_carry, (size_t)ctx->p_pad, true, st))) return rc;
     if ((rc = ensure(ctx, ctx->d_rec_id, (size_t)2 * kMaxWavesTotal))) return rc;
     if ((rc = ensure(ctx, ctx->d_rec_sum, (size_t)2 * kMaxWavesTotal))) return rc;
     if (lp.hist_lds && (rc = ensure(ctx, ctx->d_prod_slab, (size_t)lp.blocks * ctx->p_pad))) return rc;
@@ -591,7 +597,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     if (ctx->profiling) { HIPCHK(ctx, hipEventRecord(ctx->ev[3], st)); HIPCHK(ctx, hipEventRecord(ctx->ev[4], st)); }
   } else {
     if (ctx->d_cust_carry.cap < (size_t)n_customers) {
-      if ((rc = ensure(ctx, ctx->d_cust_carry, (size_t)n_customers, true))) return rc;
+      if ((rc = ensure(ctx, ctx->d_cust_carry, (size_t)n_customers, true, st))) return rc;
     }
     if (cp.lds_tables && (rc = ensure(ctx, ctx->d_cust_slab, (size_t)cp.n_streams * cp.c_pad))) return rc;
     CustArgs c;
@@ -865,6 +871,8 @@ ACMPC_API int acmpc_aggregate_lifecycle(acmpc_ctx* ctx, const int32_t* order_id,
   if ((rc = ensure(ctx, ctx->s_product_qty, (size_t)P))) return rc;
   if ((rc = ensure(ctx, ctx->s_customer_total, (size_t)n_customers))) return rc;
   hipStream_t st = nullptr;
+  // this call reports on its own input only: flags left by earlier device calls are dropped
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), st));
   if (n_lines > 0) {
     HIPCHK(ctx, hipMemcpyAsync(ctx->s_order_id.p, order_id, (size_t)n_lines * 4, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->s_product_idx.p, product_idx, (size_t)n_lines * 4, hipMemcpyHostToDevice, st));
@@ -1237,6 +1245,7 @@ ACMPC_API int acmpc_ingest_detalle(acmpc_ctx* ctx, const char* text, int64_t n_b
   if ((rc = ensure(ctx, ctx->s_product_idx, (size_t)capacity_rows))) return rc;
   if ((rc = ensure(ctx, ctx->s_qty, (size_t)capacity_rows))) return rc;
   hipStream_t st = nullptr;
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), st));   // this call reports on its own text only
   if (n_bytes > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->s_text.p, text, (size_t)n_bytes, hipMemcpyHostToDevice, st));
   rc = acmpc_ingest_detalle_device(ctx, reinterpret_cast<const char*>(ctx->s_text.p), n_bytes, ctx->s_order_id.p,
                                    ctx->s_product_idx.p, ctx->s_qty.p, capacity_rows,
@@ -1315,6 +1324,7 @@ int emit_host_impl(acmpc_ctx* ctx, const char* who, int kind, const int64_t* val
   if ((rc = ensure(ctx, ctx->s_text, (size_t)capacity + 16))) return rc;
   if (!ctx->d_ing_scalars) HIPCHK(ctx, hipMalloc((void**)&ctx->d_ing_scalars, 2 * sizeof(long long)));
   hipStream_t st = nullptr;
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), st));   // this call reports on its own rows only
   if (n_rows > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->s_emit_value.p, value, (size_t)n_rows * 8, hipMemcpyHostToDevice, st));
   rc = kind == kEmitTotals
            ? acmpc_emit_totals_device(ctx, ctx->s_emit_value.p, n_rows, (int32_t)base, style,

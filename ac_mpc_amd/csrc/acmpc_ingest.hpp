@@ -24,7 +24,9 @@ constexpr int kIngChunk = kIngThreads * kIngPerThread;  // 12 KiB per workgroup 
 constexpr int kIngWords = kIngPerThread / 4;
 constexpr int kIngPerTicket = 1;                        // consecutive chunks a workgroup takes at once
 constexpr int kIngBlocksPerCu = 5;                      // resident workgroups per CU (LDS and registers allow five)
-constexpr int kIngLook = 128;                           // lookahead kept in LDS; longest row is 120 bytes
+constexpr int kIngLook = 256;                           // lookahead kept in LDS: a statement's row may start 100 bytes
+                                                        // into its line, and the automaton looks at 128 bytes from there
+constexpr int kIngStmtReach = 100;                      // farthest a statement's row may start from its line start
 constexpr int kIngMaxRow = 120;
 constexpr uint32_t kStIngestMalformed = 8u, kStIngestCapacity = 16u;
 
@@ -56,6 +58,30 @@ __device__ __forceinline__ bool ing_digit(uint32_t c) { return c - '0' < 10u; }
 // Is the row that starts with bytes (c0, c1) a data row?
 __device__ __forceinline__ bool ing_data_row(uint32_t c0, uint32_t c1) {
   return ing_digit(c0) || c0 == '(' || c0 == '\'' || c0 == '"' || (c0 == '-' && ing_digit(c1));
+}
+
+// The one-line statement of library/consulSQL.php:30 ("insert into detalle (...) VALUES('5', '1', '1')"):
+// a line whose first six bytes are "insert" in any letter case and that has, at most kIngStmtReach bytes
+// from its start and before its newline, a '(' directly preceded (spaces allowed) by "values" in any
+// case.  Returns the offset of the first such '(' from the line start, or -1 (the header line of the dump
+// style).  `s` points at the line start in the LDS text, which ends in a sentinel newline.
+__device__ __forceinline__ bool ing_lower_is(const unsigned char* s, const char (&word)[7]) {
+  bool same = true;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) same &= (s[i] | 0x20u) == (uint32_t)word[i];
+  return same;
+}
+__device__ __forceinline__ int ing_statement_row(const unsigned char* s) {
+  if (!ing_lower_is(s, "insert")) return -1;
+  for (int j = 6; j <= kIngStmtReach; ++j) {
+    const uint32_t c = s[j];
+    if (c == '\n') return -1;
+    if (c != '(') continue;
+    int k = j - 1;
+    while (k > 0 && s[k] == ' ') --k;
+    if (k - 5 >= 6 && ing_lower_is(s + k - 5, "values")) return j;
+  }
+  return -1;
 }
 
 // Bit 7 of every byte of w that equals '\n'.
@@ -513,6 +539,11 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
       // line starts in this thread's slice, then the data rows among them (first one or two bytes)
       const int o = tid * kIngPerThread;
       unsigned long long dmask = 0;
+      // statement lines of this slice (a statement line takes at least 20 bytes: at most three start here)
+      // hand out the position of their '(' instead of the line start
+      unsigned long long smask_stmt = 0;
+      unsigned short stmt_at[3] = {0, 0, 0};
+      int n_stmt = 0;
       if (base < a.n_bytes) {
         uint32_t w[kIngWords];
 #pragma unroll
@@ -531,6 +562,11 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
           const uint32_t c0 = s_chunk[o + k];
           const uint32_t c1 = k + 1 < left ? (uint32_t)s_chunk[o + k + 1] : 0u;
           if (ing_data_row(c0, c1)) dmask |= 1ull << k;
+          else if ((c0 | 0x20u) == 'i') {
+            // (bytes past the end of the text: the sentinel newline stops the search)
+            const int at = ing_statement_row(s_chunk + o + k);
+            if (at >= 0) { dmask |= 1ull << k; stmt_at[n_stmt < 3 ? n_stmt : 2] = (unsigned short)(o + k + at); ++n_stmt; smask_stmt |= 1ull << k; }
+          }
         }
       }
       const int cnt = __popcll(dmask);
@@ -550,7 +586,15 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
       // hand the rows out one per thread: every lane of a wave then parses a row of its own, and
       // consecutive lanes write consecutive output rows
       int r = woff + incl - cnt;
-      for (unsigned long long m = dmask; m; m &= m - 1ull, ++r) s_row[r] = (unsigned short)(o + __ffsll((long long)m) - 1);
+      {
+        int si = 0;
+        for (unsigned long long m = dmask; m; m &= m - 1ull, ++r) {
+          const int k = __ffsll((long long)m) - 1;
+          const bool stmt = (smask_stmt >> k) & 1ull;
+          s_row[r] = stmt ? stmt_at[si < 3 ? si : 2] : (unsigned short)(o + k);
+          si += stmt ? 1 : 0;
+        }
+      }
       __syncthreads();
       if (n_r <= kKeep) {
         flush_parked();                                      // the chunk before: its look-back comes late, after this publish

@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
   for (long long t = t0; t < t1; ++t) {
     const long long l0 = t * kTile + (long long)lane * LPL;
     int ids[LPL], prs[LPL], qs[LPL], qh[LPL];
-    long long sn[LPL];
+    long long sn[LPL] = {};
     const bool snapped = kLife && a.line_price != nullptr;
     if (l0 + LPL <= a.n_lines) {
       load_lines<LPL>(a.order_id + l0, ids);

@@ -79,8 +79,8 @@ class consultasLote {
 
     /*
      * A column of $n elements of $tipo ("int32_t", "int64_t") in page-locked memory of the context: a
-     * worker that fills such columns in place (instead of PHP arrays, as $_SESSION['carro'] is at
-     * process/carrito.php:8-10) and passes them to acmpc_aggregate gets its copies at the PCIe rate.
+     * worker that fills such columns in place (instead of PHP arrays, as $_SESSION['producto'] is at
+     * process/carrito.php:7) and passes them to acmpc_aggregate gets its copies at the PCIe rate.
      * Index it like an FFI array; release it with LiberarColumna.
      */
     public static function ReservarColumna($tipo, $n) {

@@ -34,8 +34,10 @@ def _run(cmd, cwd=None):
 
 
 def build_library(force: bool = False) -> str:
-    srcs = [os.path.join(PKG, "csrc", "acmpc.hip"), os.path.join(PKG, "csrc", "acmpc_kernels.hpp"),
-            os.path.join(PKG, "csrc", "acmpc_ingest.hpp"), os.path.join(ROOT, "include", "acmpc.h")]
+    csrc = os.path.join(PKG, "csrc")
+    srcs = [os.path.join(csrc, "acmpc.hip")]
+    srcs += sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp"))
+    srcs.append(os.path.join(ROOT, "include", "acmpc.h"))
     if force or not _newer(LIB, srcs):
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
         _run([HIPCC, *HIP_FLAGS, "-shared", "-o", LIB, srcs[0]])

@@ -30,7 +30,7 @@
  * each hold their own context on the same GPU.
  *
  * Limits (larger counts return ACMPC_E_INVALID): n_orders < 2^31 (order ids are
- * INT, store.sql:98,159), n_lines <= 2^40, n_products <= 2^28 (2^24 for a code
+ * INT, store.sql:98,159), n_lines <= 2^40, n_products <= 2^28 (2^21 for a code
  * list), n_customers <= 2^30, 2^44 bytes of text per ingest call.
  */
 #ifndef ACMPC_H
@@ -125,8 +125,9 @@ int acmpc_aggregate(acmpc_ctx* ctx,
                     int64_t* out_customer_total_cents);
 
 /*
- * Same computation on DEVICE-resident columns and outputs (16-byte aligned
- * device pointers on the context's device).  Work is enqueued on `hip_stream`
+ * Same computation on DEVICE-resident columns and outputs (device pointers on
+ * the context's device; the four input columns and d_out_order_total_cents
+ * 16-byte aligned, the other two outputs 8-byte aligned).  Work is enqueued on `hip_stream`
  * (a hipStream_t; NULL = the default stream) and the call returns without
  * waiting.  Uses a workspace owned by the context: calls on one context must
  * not overlap in time.  Contract violations are reported by acmpc_status().
@@ -200,7 +201,10 @@ int acmpc_aggregate_lifecycle_device(acmpc_ctx* ctx,
 
 /*
  * Wait for `hip_stream`, then store in *flags the OR of ACMPC_ST_* bits raised
- * by device calls since the previous acmpc_status(), and clear them.
+ * by device calls since the previous acmpc_status(), and clear them.  The flags
+ * of all *_device calls of a context accumulate in one word until they are
+ * collected here; the host-pointer entry points start from a clean word and
+ * report on their own input only.
  * Returns ACMPC_OK when *flags == 0, ACMPC_E_DATA otherwise.
  * Stands where the reference tests the result of mysqli_query and dies
  * (library/consulSQL.php:18-19): the device calls only enqueue work, so their
@@ -253,7 +257,7 @@ int acmpc_lines_geometry(acmpc_ctx* ctx, int32_t* n_workgroups, int32_t* waves_p
  * *out is 16-byte aligned, belongs to the context and is released by
  * acmpc_host_free() or, at the latest, by acmpc_destroy().
  * Replaces the PHP arrays in which the reference holds a cart
- * ($_SESSION['carro'], process/carrito.php:8-10; process/confirmcompra.php:35).
+ * ($_SESSION['producto'], process/carrito.php:7; process/confirmcompra.php:35).
  */
 int acmpc_host_alloc(acmpc_ctx* ctx, int64_t n_bytes, void** out);
 int acmpc_host_free(acmpc_ctx* ctx, void* p);
@@ -262,25 +266,29 @@ int acmpc_host_free(acmpc_ctx* ctx, void* p);
  * Text ingest: `detalle` rows as SQL-dump / CSV text -> the three int32 columns.
  *
  * Accepted text (the shapes the reference itself writes):
- *   - the statement process/confirmcompra.php:36 sends through library/consulSQL.php:29-30:
+ *   - the statement process/confirmcompra.php:36 sends through library/consulSQL.php:29-30, one
+ *     statement per line (a query log of checkouts):
  *       insert into detalle (NumPedido, CodigoProd, CantidadProductos) VALUES('5', '1', '1')
  *   - the phpMyAdmin dump style of store.sql:88-89,125-128: an "INSERT INTO `t` (...) VALUES" header
  *     line followed by one "(5, '1', 1)," row per line, the last ending in ";"
  *   - plain comma- or tab-separated rows, one per line
- * Grammar.  A row starts at offset 0 or after '\n'.  It is a DATA row iff its first byte is a
- * digit, '-' followed by a digit, '(' or a quote; any other line (INSERT header, "--" comment,
- * blank) is skipped.
+ * Grammar.  A line starts at offset 0 or after '\n'.  It holds a DATA row iff its first byte is a
+ * digit, '-' followed by a digit, '(' or a quote (the row starts with the line), or it is a
+ * STATEMENT line: its first six bytes are "insert" in any letter case and, at most 100 bytes from
+ * the line start and before the '\n', there is a '(' directly preceded (spaces allowed between) by
+ * "values" in any letter case; the row then starts at the first such '('.  Any other line (the INSERT
+ * header of the dump style, "--" comment, blank) is skipped.
  *   row  := ['('] sp int sp sep sp code sp sep sp int sp [')'] [','|';'] ['\r'] ('\n' | end of text)
  *   int  := [q] ['-'] digit{1,10} [q]        must fit int32; q is ' or " and must match
  *   code := q bytes q  (no q, no '\n' inside; a doubled q is not accepted)
  *         | bytes up to one of , \t space \r \n )           0..30 bytes (varchar(30), store.sql:99)
- *   sep  := ',' | '\t'      sp := ' '*      a row is at most 120 bytes before its '\n'
+ *   sep  := ',' | '\t'      sp := ' '*      a row is at most 120 bytes from its first byte to its '\n'
  * A data row that does not match yields (0, -1, 0), is counted, and raises
  * ACMPC_ST_INGEST_MALFORMED.  CodigoProd is matched byte for byte against the code list; an
  * unknown code becomes product_idx -1 (it adds nothing: process/carrito.php:13-14).
- * Rows keep their order in the text.  VALUES rows that share a line with the INSERT header, and
- * several rows on one line, are not accepted (phpMyAdmin and mysqldump --skip-extended-insert
- * write one row per line).
+ * Rows keep their order in the text.  Several rows on one line (mysqldump's extended inserts) are
+ * not accepted: a statement line carries one row, and a second row behind it makes that row
+ * malformed (phpMyAdmin and mysqldump --skip-extended-insert write one row per line).
  * ---------------------------------------------------------------------- */
 
 /* Product code list: n_products entries of 32 bytes each, NUL padded, codes of at most 30 bytes

@@ -8,21 +8,24 @@
  * The text shapes accepted here are the ones the reference itself writes:
  *   - the statement of process/confirmcompra.php:36 through library/consulSQL.php:29-30,
  *       insert into detalle (NumPedido, CodigoProd, CantidadProductos) VALUES('5', '1', '1')
- *     (all three values quoted),
+ *     (all three values quoted; one statement per line, as a query log holds them),
  *   - the phpMyAdmin dump style of the reference's own store.sql:88-89,125-128: an
  *       INSERT INTO `t` (...) VALUES
  *     header line followed by one "(v, 'v', v)," row per line, the last one ending in ";",
  *   - plain comma- or tab-separated rows, one per line (SELECT ... INTO OUTFILE).
  *
  * Grammar (shared with the device kernels, which must produce identical columns):
- *   A row starts at offset 0 or after '\n'.  It is a DATA row iff its first byte is a digit, '-'
- *   followed by a digit, '(' or a quote; every other line (INSERT header, "--" comments, blanks)
- *   is skipped.
+ *   A line starts at offset 0 or after '\n'.  It holds a DATA row iff its first byte is a digit, '-'
+ *   followed by a digit, '(' or a quote (the row starts with the line), or it is a STATEMENT line: its
+ *   first six bytes are "insert" in any letter case and, at most 100 bytes from the line start and before
+ *   the '\n', there is a '(' directly preceded (spaces allowed between) by "values" in any letter case;
+ *   the row then starts at the first such '('.  Every other line (the INSERT header of the dump style,
+ *   "--" comments, blanks) is skipped.
  *   row   := ['('] sp int sp sep sp code sp sep sp int sp [')'] [',' | ';'] ['\r'] ('\n' | end)
  *   int   := [q] ['-'] digit{1,10} [q]      value must fit int32; q is ' or " and must match
  *   code  := q bytes-until-q q  |  bytes until one of , \t space \r \n )      0..30 bytes
  *   sep   := ',' | '\t'         sp := ' '*
- *   A data row longer than 120 bytes (before its '\n') or that does not match is MALFORMED: it yields (0, -1, 0) and is counted.
+ *   A data row longer than 120 bytes (from its first byte to before its '\n') or that does not match is MALFORMED: it yields (0, -1, 0) and is counted.
  *   CodigoProd is looked up by exact bytes in the product code list; unknown codes give -1
  *   (an unmatched code returns no row at process/carrito.php:13-14).
  */
@@ -36,12 +39,27 @@ static int code_len(const char* c) { int n = 0; while (n < 32 && c[n]) ++n; retu
 
 static int is_digit(unsigned char c) { return c >= '0' && c <= '9'; }
 
-static int is_data_row(const unsigned char* t, int64_t n, int64_t p)
+static int lower_is(const unsigned char* t, const char* word)
+{
+  for (int i = 0; word[i]; ++i) if ((t[i] | 0x20) != (unsigned char)word[i]) return 0;
+  return 1;
+}
+
+/* Offset of the data row of the line [p, e), or -1 when the line holds none. */
+static int64_t data_row_start(const unsigned char* t, int64_t p, int64_t e)
 {
   unsigned char c = t[p];
-  if (is_digit(c) || c == '(' || c == '\'' || c == '"') return 1;
-  if (c == '-' && p + 1 < n && is_digit(t[p + 1])) return 1;
-  return 0;
+  if (is_digit(c) || c == '(' || c == '\'' || c == '"') return p;
+  if (c == '-' && p + 1 < e && is_digit(t[p + 1])) return p;
+  if (e - p >= 6 && lower_is(t + p, "insert")) {      /* the statement of library/consulSQL.php:30 */
+    for (int64_t j = p + 6; j < e && j - p <= 100; ++j) {
+      if (t[j] != '(') continue;
+      int64_t k = j - 1;
+      while (k > p && t[k] == ' ') --k;
+      if (k - 5 >= p + 6 && lower_is(t + k - 5, "values")) return j;
+    }
+  }
+  return -1;
 }
 
 /* Parses one int field at *pp; returns 0 on success. */
@@ -98,10 +116,11 @@ ORACLE_API int64_t oracle_ingest_detalle(const char* text, int64_t n_bytes, cons
     int64_t start = p;
     int64_t e = p;
     while (e < n_bytes && t[e] != '\n') ++e;          /* e: the row's '\n' or end of text */
-    if (e > start && is_data_row(t, n_bytes, start)) {
+    const int64_t rs = e > start ? data_row_start(t, start, e) : -1;
+    if (rs >= 0) {
       int32_t a = 0, q = 0, pi = -1;
       int ok = 1;
-      int64_t c = start;
+      int64_t c = rs;
       if (t[c] == '(') ++c;
       skip_sp(t, e, &c);
       if (parse_int(t, e, &c, &a)) ok = 0;
@@ -132,7 +151,7 @@ ORACLE_API int64_t oracle_ingest_detalle(const char* text, int64_t n_bytes, cons
         if (c < e && t[c] == '\r') ++c;
         if (c != e) ok = 0;
       }
-      if (e - start > 120) ok = 0;                    /* longest row the grammar admits */
+      if (e - rs > 120) ok = 0;                    /* longest row the grammar admits */
       if (ok) {
         uint64_t h = 1469598103934665603ull;
         for (int k = 0; k < clen; ++k) h = (h ^ cs[k]) * 1099511628211ull;

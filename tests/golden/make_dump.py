@@ -6,8 +6,9 @@ The layout copies the reference's own dump, store.sql:88-89,125-128 (header line
 between rows, ";" after the last), split into several INSERT statements as phpMyAdmin does for long tables.
 The reference ships no `detalle` rows, so the rows are the synthetic ones; product codes are the seed codes
 '1','2','3' (store.sql:126-128) followed by 'SKU-00003', ...  A second file, detalle_insert_stmt.sql, holds
-the first 40 rows in the form process/confirmcompra.php:36 sends them (every value quoted, one statement per row
-- here one row per line after a header, the form the ingest accepts).
+the first 40 rows as the literal statements process/confirmcompra.php:36 sends through
+library/consulSQL.php:30, one statement per line (the form a query log holds them in): every value quoted,
+CantidadProductos always '1', no terminator.
 """
 import os
 import numpy as np
@@ -29,8 +30,8 @@ def main():
         out.append(",\n".join(rows) + ";")
         out.append("")
     open(os.path.join(HERE, "detalle_dump.sql"), "w", newline="\n").write("\n".join(out) + "\n")
-    stmt = ["insert into detalle (NumPedido, CodigoProd, CantidadProductos) VALUES"]
-    stmt += [f"('{int(a)}', '{code_of(int(p))}', '1')" for a, p in zip(oid[:40], pidx[:40])]
+    stmt = [f"insert into detalle (NumPedido, CodigoProd, CantidadProductos) VALUES('{int(a)}', '{code_of(int(p))}', '1')"
+            for a, p in zip(oid[:40], pidx[:40])]
     open(os.path.join(HERE, "detalle_insert_stmt.sql"), "w", newline="\n").write("\n".join(stmt) + "\n")
     print("rows", oid.size)
 

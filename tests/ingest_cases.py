@@ -9,6 +9,10 @@ _ROW = re.compile(r"\(? *" + _INT.format(n=1) + r" *[,\t] *" + _CODE + r" *[,\t]
                   r" *\)?[,;]?\r?$")
 
 
+# "insert" + anything without a VALUES( in it + VALUES + spaces + "(": the first such parenthesis
+_STMT = re.compile(rb"(?i:insert)(?:(?!(?i:values) *\()[^\n])*?(?i:values) *\(")
+
+
 def code_of(p: int) -> str:
     return str(p + 1) if p < 3 else f"SKU-{p:05d}"
 
@@ -26,7 +30,11 @@ def reference_parse(text: bytes, codes):
         c0 = ln[:1]
         data = c0.isdigit() or c0 in (b"(", b"'", b'"') or (c0 == b"-" and ln[1:2].isdigit())
         if not data:
-            continue
+            # the one-line statement of library/consulSQL.php:30: the row starts at the '(' after VALUES
+            m = _STMT.match(ln) if ln[:6].lower() == b"insert" else None
+            if m is None or m.end() - 1 > 100:
+                continue
+            ln = ln[m.end() - 1:]
         s = ln.decode("latin-1")
         m = _ROW.match(s) if len(ln) <= 120 else None
         ok = m is not None
@@ -63,7 +71,27 @@ def render(oid, pidx, qty, style: str, rng=None) -> bytes:
     if style == "quoted":
         body = "".join(f"('{a}', \"{code_of(p) if p >= 0 else 'NOPE'}\", '{q}')\n" for a, p, q in zip(oid, pidx, qty))
         return ("insert into detalle (NumPedido, CodigoProd, CantidadProductos) VALUES\n" + body).rstrip("\n").encode("latin-1")
+    if style == "statements":           # one statement per line, exactly as library/consulSQL.php:30 builds it
+        return ("".join(f"insert into detalle (NumPedido, CodigoProd, CantidadProductos) VALUES('{a}', '{code_of(p) if p >= 0 else 'NOPE'}', '{q}')\n"
+                        for a, p, q in zip(oid, pidx, qty))).encode("latin-1")
     raise ValueError(style)
+
+
+def statement_prefix(rng) -> str:
+    """A random front part of a statement line: mostly the reference's own (library/consulSQL.php:30), sometimes
+    other letter cases, spacing, paddings that push the '(' past the 100-byte reach, or no VALUES( at all."""
+    r = rng.random()
+    if r < 0.5:
+        return "insert into detalle (NumPedido, CodigoProd, CantidadProductos) VALUES"
+    if r < 0.65:
+        return "INSERT INTO `detalle` (`NumPedido`, `CodigoProd`, `CantidadProductos`) VALUES" + " " * int(rng.integers(0, 30))
+    if r < 0.75:
+        return "Insert into detalle" + " " * int(rng.integers(1, 90)) + "values "
+    if r < 0.85:
+        return "insert into detalle (a values (b) c) VALUES "      # the first VALUES( wins
+    if r < 0.92:
+        return "insertvalues"
+    return "insert into detalle (NumPedido) value"                  # not a statement row: skipped
 
 
 EDGE_TEXT = (
@@ -90,10 +118,15 @@ EDGE_TEXT = (
     b"x,1,1\n"                                   # not a data row: skipped
     b"-- 18,1,1\n"                               # comment: skipped
     b"-5,2,1\n"
+    b"insert into detalle (NumPedido, CodigoProd, CantidadProductos) VALUES('20', '1', '1')\n"   # library/consulSQL.php:30
+    b"INSERT INTO `detalle` (`NumPedido`, `CodigoProd`, `CantidadProductos`) VALUES (21, '2', 3);\r\n"
+    b"insert into detalle (NumPedido, CodigoProd, CantidadProductos) VALUES('22', '1' '1')\n"    # malformed row in a statement
+    b"insert into detalle (NumPedido) select 23\n"                                             # no VALUES(: skipped
+    b"Insert Into detalle Values   ('24',\"3\",'2')\n"
     b"(19, \"2\", 7)"                            # last row without newline
 )
 EDGE_CODES = ["1", "2", "3", "SKU-00003"]
 EDGE_EXPECT = [(5, 0, 1), (5, 1, 1), (0, -1, 0), (6, 3, 2), (7, 0, 3), (7, 1, -4), (8, 2, 1), (9, -1, 1), (10, -1, 1),
                (11, -1, 1), (0, -1, 0), (0, -1, 0), (0, -1, 0), (0, -1, 0), (-2147483648, 0, 2147483647), (0, -1, 0),
-               (0, -1, 0), (-5, 1, 1), (19, 1, 7)]
-EDGE_BAD = 7
+               (0, -1, 0), (-5, 1, 1), (20, 0, 1), (21, 1, 3), (0, -1, 0), (24, 2, 2), (19, 1, 7)]
+EDGE_BAD = 8

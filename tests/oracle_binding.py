@@ -12,6 +12,18 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 
 
+def _pack_codes(codes) -> np.ndarray:
+    """The code list as the C oracle takes it: 32 bytes per code, NUL padded (varchar(30), store.sql:110).
+    Packed here, not with the product's helper, so that the checker shares no code with what it checks."""
+    out = np.zeros((len(codes), 32), np.uint8)
+    for i, code in enumerate(codes):
+        raw = code if isinstance(code, (bytes, bytearray)) else str(code).encode("utf-8")
+        if len(raw) > 30:
+            raise ValueError(f"code {i} is longer than 30 bytes")
+        out[i, :len(raw)] = np.frombuffer(bytes(raw), np.uint8)
+    return out
+
+
 class Oracle:
     def __init__(self):
         if not os.path.exists(ORACLE_LIB):
@@ -109,8 +121,7 @@ class Oracle:
 
     def ingest(self, text: bytes, codes, capacity=None):
         """Parse `detalle` text with the C oracle; returns (order_id, product_idx, qty, n_rows, n_malformed)."""
-        from ac_mpc_amd.ingesta import empaquetar_codigos
-        packed = empaquetar_codigos(codes)
+        packed = _pack_codes(codes)
         if capacity is None:
             capacity = text.count(b"\n") + 1
         oid = np.empty(capacity, np.int32)
@@ -131,9 +142,8 @@ class Oracle:
         return buf.raw[:min(n, cap)]
 
     def emit_stock(self, product_qty, codes, style) -> bytes:
-        from ac_mpc_amd.ingesta import empaquetar_codigos
         v = np.ascontiguousarray(product_qty, np.int64)
-        packed = empaquetar_codigos(codes)
+        packed = _pack_codes(codes)
         cap = v.size * 110 + 1
         buf = C.create_string_buffer(cap)
         n = int(self.lib.oracle_emit_stock(v.ctypes.data, v.size, packed.ctypes.data, style, buf, cap))

@@ -176,7 +176,7 @@ def test_text_paths_with_poisoned_device_buffers(oracle):
         oid = np.sort(rng.integers(5, 5 + max(1, n // 3), size=n)).astype(np.int32)
         pidx = rng.integers(-1, p, size=n).astype(np.int32)
         qty = rng.integers(-9, 10_000, size=n).astype(np.int32)
-        style = str(rng.choice(["dump", "csv", "tsv_crlf", "quoted"]))
+        style = str(rng.choice(["dump", "csv", "tsv_crlf", "quoted", "statements"]))
         text = ic.render(oid.tolist(), pidx.tolist(), qty.tolist(), style) if n else b"-- nothing\n"
         tb = torch.frombuffer(bytearray(text + b"\0" * 16), dtype=torch.uint8).to(dev)[: len(text)]
         cap = n + 5

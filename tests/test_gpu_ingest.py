@@ -52,7 +52,7 @@ def test_edge_rows_on_device_match_hand_expectations(motor):
     assert list(zip(oid.tolist(), pidx.tolist(), qty.tolist())) == ic.EDGE_EXPECT
 
 
-@pytest.mark.parametrize("style", ["dump", "csv", "tsv_crlf", "quoted"])
+@pytest.mark.parametrize("style", ["dump", "csv", "tsv_crlf", "quoted", "statements"])
 @pytest.mark.parametrize("n", [1, 63, 5000, 400_003])
 def test_styles_and_sizes(motor, oracle, style, n):
     d = oracle.synth(n, 10_000, 50, zipf=1, qty_mode=1)
@@ -81,6 +81,8 @@ def test_fuzzed_text_row_for_row(motor, oracle):
             a, q = int(rng.integers(-50, 2**31)), int(rng.integers(-3, 99))
             c = codes[int(rng.integers(0, len(codes)))] if rng.random() < 0.8 else "zz"
             ln = rng.choice([f"({a}, '{c}', {q}),", f"{a},{c},{q}", f"'{a}'\t\"{c}\"\t'{q}'\r", f"( {a} ,'{c}' , {q} );"]).encode("latin-1")
+            if rng.random() < 0.25:                    # the same row behind a statement's front part
+                ln = ic.statement_prefix(rng).encode("latin-1") + ln
             if rng.random() < 0.3:
                 k = int(rng.integers(0, len(ln)))
                 ln = ln[:k] + bytes([alphabet[int(rng.integers(0, len(alphabet)))]]) + ln[k + 1:]

@@ -7,6 +7,15 @@ from tests import lifecycle_cases as lc
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def nuevo_motor():
+    """A fresh context per test (options and product tables differ between them), closed afterwards."""
+    from ac_mpc_amd import MotorLote
+    m = MotorLote(0)
+    yield m
+    m.cerrar()
+
+
 def _run_host(motor, d, n_customers, cols, mode):
     return motor.agregar(d["order_id"], d["product_idx"], d["qty"], d["order_customer"], d["order_id_base"], n_customers,
                          precio_linea=cols["line_price"], estado_pedido=cols["order_state"],
@@ -22,10 +31,9 @@ def _expect(oracle, d, n_customers, price, cols, mode):
 
 
 @pytest.mark.parametrize("case", lc.fixture()["cases"], ids=lambda c: c["name"])
-def test_known_answers(case):
-    from ac_mpc_amd import MotorLote
+def test_known_answers(case, nuevo_motor):
     d = lc.fixture()
-    m = MotorLote(0)
+    m = nuevo_motor
     m.cargar_productos(np.array(case.get("price_cents_now", d["price_cents"]), np.int64))
     tot, pq, ct = m.agregar(d["order_id"], d["product_idx"], d["qty"], d["order_customer"], d["order_id_base"],
                             d["n_customers"], precio_linea=case.get("line_price"), estado_pedido=case.get("order_state"),
@@ -35,11 +43,10 @@ def test_known_answers(case):
 
 @pytest.mark.parametrize("mask", lc.MASKS)
 @pytest.mark.parametrize("n_lines,p,c", [(1, 3, 1), (255, 10, 7), (1000, 100, 50), (65_537, 10_000, 100_000), (1_000_003, 10_000, 100_000)])
-def test_random_columns_all_masks(oracle, mask, n_lines, p, c):
-    from ac_mpc_amd import MotorLote
+def test_random_columns_all_masks(oracle, mask, n_lines, p, c, nuevo_motor):
     d = oracle.synth(n_lines, p, c, qty_mode=1)
     price = oracle.synth_prices(p)
-    m = MotorLote(0)
+    m = nuevo_motor
     m.cargar_productos(price)
     for mode in (0, 1):
         cols = lc.columns(d, n_lines + mode, mask)
@@ -49,11 +56,10 @@ def test_random_columns_all_masks(oracle, mask, n_lines, p, c):
             assert np.array_equal(g, e), (name, mask, mode)
 
 
-def test_wide_values_wrap_like_the_oracle(oracle):
-    from ac_mpc_amd import MotorLote
+def test_wide_values_wrap_like_the_oracle(oracle, nuevo_motor):
     d = oracle.synth(20_000, 64, 33, qty_mode=1)
     price = oracle.synth_prices(64)
-    m = MotorLote(0)
+    m = nuevo_motor
     m.cargar_productos(price)
     for mode in (0, 1):
         cols = lc.columns(d, 99 + mode, "psd", wide=True)
@@ -64,9 +70,8 @@ def test_wide_values_wrap_like_the_oracle(oracle):
 
 @pytest.mark.parametrize("big_tables", [False, True])
 @pytest.mark.parametrize("any_order", [False, True])
-def test_table_modes_and_any_order(oracle, big_tables, any_order):
+def test_table_modes_and_any_order(oracle, big_tables, any_order, nuevo_motor):
     """Price table too large for LDS (global-table kernels) and rows in any order."""
-    from ac_mpc_amd import MotorLote
     p, c = (60_000, 700_000) if big_tables else (500, 2_000)
     d = oracle.synth(300_000, p, c, qty_mode=1)
     price = oracle.synth_prices(p)
@@ -77,16 +82,15 @@ def test_table_modes_and_any_order(oracle, big_tables, any_order):
         for k in ("order_id", "product_idx", "qty"):
             d[k] = d[k][perm]
         cols["line_price"] = cols["line_price"][perm]
-    m = MotorLote(0)
+    m = nuevo_motor
     m.cargar_productos(price)
     m.orden_lineas(any_order)
     got = _run_host(m, d, c, cols, 1)
     assert all(np.array_equal(g, e) for g, e in zip(got, exp))
 
 
-def test_orders_without_lines_still_get_their_discount(motor_small=None):
-    from ac_mpc_amd import MotorLote
-    m = MotorLote(0)
+def test_orders_without_lines_still_get_their_discount(nuevo_motor):
+    m = nuevo_motor
     m.cargar_productos(np.array([100, 200], np.int64))
     z = np.zeros(0, np.int32)
     tot, pq, ct = m.agregar(z, z, z, np.array([0, 1, 0], np.int32), 5, 2, descuento=np.array([1, 2, 3], np.int32))
@@ -98,9 +102,9 @@ def test_orders_without_lines_still_get_their_discount(motor_small=None):
     assert tot.tolist() == [-100, 400, -300] and pq.tolist() == [0, 3] and ct.tolist() == [-100, 400]
 
 
-def test_bad_lifecycle_arguments():
-    from ac_mpc_amd import ErrorLote, MotorLote
-    m = MotorLote(0)
+def test_bad_lifecycle_arguments(nuevo_motor):
+    from ac_mpc_amd import ErrorLote
+    m = nuevo_motor
     m.cargar_productos(np.array([100], np.int64))
     one = np.array([5], np.int32)
     with pytest.raises(ErrorLote):
@@ -109,11 +113,11 @@ def test_bad_lifecycle_arguments():
         m.agregar(one, np.zeros(1, np.int32), np.ones(1, np.int32), np.zeros(1, np.int32), 5, 1, precio_linea=np.ones(3, np.int64))
 
 
-def test_device_columns_at_bench_size(oracle):
+def test_device_columns_at_bench_size(oracle, nuevo_motor):
     """100 M lines with every lifecycle column, device resident, against the C oracle."""
     import torch
-    from ac_mpc_amd import MotorLote, sintetico
-    m = MotorLote(0)
+    from ac_mpc_amd import sintetico
+    m = nuevo_motor
     dev = torch.device("cuda", 0)
     n, p, c = 100_000_000, 10_000, 100_000
     price = oracle.synth_prices(p)

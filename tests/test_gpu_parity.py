@@ -238,7 +238,7 @@ def test_sizes_beyond_the_limits_are_refused_before_anything_is_allocated(motor)
     assert rc == _lib.E_INVALID
     price = (C.c_int64 * 1)(1)
     assert lib.acmpc_set_products(ctx, price, (1 << 28) + 1) == _lib.E_INVALID
-    assert lib.acmpc_set_product_codes(ctx, C.create_string_buffer(32), (1 << 24) + 1) == _lib.E_INVALID
+    assert lib.acmpc_set_product_codes(ctx, C.create_string_buffer(32), (1 << 21) + 1) == _lib.E_INVALID
     tot, pq, ct = motor.agregar([5, 6], [0, 1], [1, 1], [0, 0], 5, 1)      # the context still works
     assert tot.tolist() == [100, 200] and pq.tolist() == [1, 1] and ct.tolist() == [300]
 

@@ -35,7 +35,7 @@ def test_committed_dump_reproduces_the_columns(oracle):
     assert qty.tolist() == [1] * 40                    # process/confirmcompra.php:36 always writes '1'
 
 
-@pytest.mark.parametrize("style", ["dump", "csv", "tsv_crlf", "quoted"])
+@pytest.mark.parametrize("style", ["dump", "csv", "tsv_crlf", "quoted", "statements"])
 def test_styles_round_trip(oracle, style):
     d = oracle.synth(20_000, 500, 50, zipf=1, qty_mode=1)
     pidx = d["product_idx"].copy()
@@ -60,6 +60,8 @@ def test_fuzzed_rows_agree_with_regex_reference(oracle):
             c = codes[int(rng.integers(0, len(codes)))] if rng.random() < 0.8 else "zz"
             ln = rng.choice([f"({a}, '{c}', {q}),", f"{a},{c},{q}", f"'{a}'\t\"{c}\"\t'{q}'\r", f"( {a} ,'{c}' , {q} );"])
             ln = ln.encode("latin-1")
+            if rng.random() < 0.25:                    # the same row behind a statement's front part
+                ln = ic.statement_prefix(rng).encode("latin-1") + ln
             if rng.random() < 0.3:                     # corrupt one byte
                 k = int(rng.integers(0, len(ln)))
                 ln = ln[:k] + bytes([alphabet[int(rng.integers(0, len(alphabet)))]]) + ln[k + 1:]
