@@ -17,7 +17,7 @@ def _pack_codes(codes) -> np.ndarray:
     Packed here, not with the product's helper, so that the checker shares no code with what it checks."""
     out = np.zeros((len(codes), 32), np.uint8)
     for i, code in enumerate(codes):
-        raw = code if isinstance(code, (bytes, bytearray)) else str(code).encode("utf-8")
+        raw = code if isinstance(code, (bytes, bytearray)) else str(code).encode("latin-1")
         if len(raw) > 30:
             raise ValueError(f"code {i} is longer than 30 bytes")
         out[i, :len(raw)] = np.frombuffer(bytes(raw), np.uint8)
