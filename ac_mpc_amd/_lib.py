@@ -19,7 +19,7 @@ EXPORTS = (
     "acmpc_synth_generate_device", "acmpc_set_product_codes", "acmpc_ingest_detalle_device", "acmpc_ingest_detalle",
     "acmpc_aggregate_lifecycle", "acmpc_aggregate_lifecycle_device",
     "acmpc_emit_totals_device", "acmpc_emit_stock_device", "acmpc_emit_totals", "acmpc_emit_stock",
-    "acmpc_host_alloc", "acmpc_host_free",
+    "acmpc_host_alloc", "acmpc_host_free", "acmpc_aggregate_device_noalloc",
 )
 
 OK, E_INVALID, E_HIP, E_ALIGN, E_DATA, E_STATE, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
@@ -94,6 +94,8 @@ def load() -> C.CDLL:
     lib.acmpc_aggregate.restype = C.c_int
     lib.acmpc_aggregate_device.argtypes = [vp, vp, vp, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp]
     lib.acmpc_aggregate_device.restype = C.c_int
+    lib.acmpc_aggregate_device_noalloc.argtypes = [vp, vp, vp, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp]
+    lib.acmpc_aggregate_device_noalloc.restype = C.c_int
     lib.acmpc_status.argtypes = [vp, vp, u32p]
     lib.acmpc_status.restype = C.c_int
     lib.acmpc_set_option.argtypes = [vp, C.c_int, i64]

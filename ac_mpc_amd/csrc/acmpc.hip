@@ -29,6 +29,33 @@ constexpr int64_t kMaxTextBytes = 1ll << 44;
 
 char g_init_error[512] = "no error";
 
+// ---- workspace of the allocation-free entry point (acmpc_aggregate_device_noalloc) ----------------
+// One fixed array in the code object; every GPU the library runs on holds its own copy, at its own
+// address, until the process ends.  `scratch` is only a host-side stand-in for that array: the address a
+// kernel can use is asked for once per device (acmpc_init, with that device current) and kept in
+// g_scratch_ptr; host code uses that pointer, never the array's name.
+constexpr int32_t kNaMaxProducts = 16380;                  // padded table (P + 1 rounded up to 4) <= 16384
+constexpr int32_t kNaMaxCustomers = 131072;
+constexpr size_t kNaProdSlabBytes = (size_t)256 * 16384 * 4;          // one 32-bit slab per workgroup of the line pass
+constexpr size_t kNaCustSlabBytes = (size_t)44 << 20;                 // one 32-bit slab per stream of the customer pass
+constexpr size_t kNaProdCarryBytes = (size_t)16384 * 8;
+constexpr size_t kNaCustCarryBytes = (size_t)kNaMaxCustomers * 8;
+constexpr size_t kNaRecBytes = (size_t)2 * kMaxWavesTotal * 8;        // each of the four record / edge arrays
+constexpr size_t kNaOffProdSlab = 0;
+constexpr size_t kNaOffCustSlab = kNaOffProdSlab + kNaProdSlabBytes;
+constexpr size_t kNaOffProdCarry = kNaOffCustSlab + kNaCustSlabBytes;
+constexpr size_t kNaOffCustCarry = kNaOffProdCarry + kNaProdCarryBytes;
+constexpr size_t kNaOffRecId = kNaOffCustCarry + kNaCustCarryBytes;
+constexpr size_t kNaOffRecSum = kNaOffRecId + kNaRecBytes;
+constexpr size_t kNaOffEdgeIdx = kNaOffRecSum + kNaRecBytes;
+constexpr size_t kNaOffEdgeTotal = kNaOffEdgeIdx + kNaRecBytes;
+constexpr size_t kScratchBytes = kNaOffEdgeTotal + kNaRecBytes;       // 61.4 MiB
+static_assert(kNaOffCustSlab % 256 == 0 && kNaOffProdCarry % 256 == 0 && kNaOffCustCarry % 256 == 0 &&
+              kNaOffRecId % 256 == 0 && kNaRecBytes % 256 == 0, "scratch regions stay 256-byte aligned");
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};           // device address of `scratch` on every device seen
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -388,7 +415,10 @@ int launch_lines_any(acmpc_ctx* ctx, const LinesPlan& pl, size_t lds_bytes, cons
 int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32_t* d_product_idx,
                           const int32_t* d_qty, int64_t n_lines, const int32_t* d_order_customer,
                           int64_t n_orders, int32_t base, int32_t n_customers, int64_t* d_tot,
-                          int64_t* d_pq, int64_t* d_ct, hipStream_t st, const acmpc_lifecycle* life = nullptr) {
+                          int64_t* d_pq, int64_t* d_ct, hipStream_t st, const acmpc_lifecycle* life = nullptr,
+                          unsigned char* fixed_ws = nullptr) {
+  // fixed_ws: null = the context's own workspace, grown with hipMalloc as needed; otherwise the device
+  // address of the fixed scratch array, and this call allocates nothing (and refuses what does not fit).
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_aggregate_device: null context");
   const int64_t* d_line_price = life ? life->line_price_cents : nullptr;
   const uint8_t* d_state = life ? life->order_state : nullptr;
@@ -420,7 +450,43 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
   ENTER_DEVICE(ctx);
 
   const int32_t P = ctx->n_products;
-  if (ctx->carry_dirty) { int rc = clear_carries(ctx, st); if (rc) return rc; }
+  // the workspace this call uses
+  struct {
+    uint32_t* prod_slab; unsigned long long* prod_carry; int32_t* rec_id; int64_t* rec_sum;
+    uint32_t* edge_idx; int64_t* edge_total; uint32_t* cust_slab; unsigned long long* cust_carry; uint32_t* status;
+  } w = {};
+  w.status = ctx->d_status;
+  if (fixed_ws) {
+    if (life || ctx->line_order != ACMPC_ORDER_GROUPED || ctx->force_global_tables)
+      return fail(ctx, ACMPC_E_INVALID, "the allocation-free entry point serves the grouped path without lifecycle columns only");
+    if (P > kNaMaxProducts || n_customers > kNaMaxCustomers)
+      return fail(ctx, ACMPC_E_INVALID, "the allocation-free entry point takes at most %d products and %d customers (have %d, %d)",
+                  kNaMaxProducts, kNaMaxCustomers, P, n_customers);
+    w.prod_slab = reinterpret_cast<uint32_t*>(fixed_ws + kNaOffProdSlab);
+    w.cust_slab = reinterpret_cast<uint32_t*>(fixed_ws + kNaOffCustSlab);
+    w.prod_carry = reinterpret_cast<unsigned long long*>(fixed_ws + kNaOffProdCarry);
+    w.cust_carry = reinterpret_cast<unsigned long long*>(fixed_ws + kNaOffCustCarry);
+    w.rec_id = reinterpret_cast<int32_t*>(fixed_ws + kNaOffRecId);
+    w.rec_sum = reinterpret_cast<int64_t*>(fixed_ws + kNaOffRecSum);
+    w.edge_idx = reinterpret_cast<uint32_t*>(fixed_ws + kNaOffEdgeIdx);
+    w.edge_total = reinterpret_cast<int64_t*>(fixed_ws + kNaOffEdgeTotal);
+    // The array is shared by every call on this GPU and keeps the last call's contents: the 64-bit carry
+    // cells must start at zero (everything else is written before it is read).
+    HIPCHK(ctx, hipMemsetAsync(w.prod_carry, 0, kNaProdCarryBytes, st));
+    HIPCHK(ctx, hipMemsetAsync(w.cust_carry, 0, kNaCustCarryBytes, st));
+  } else if (ctx->carry_dirty) { int rc = clear_carries(ctx, st); if (rc) return rc; }
+  // one workspace buffer: from the context (allocating) or checked against its fixed region
+  auto need = [&](auto& buf, auto*& ptr, size_t n, size_t fixed_bytes, bool zero_new) -> int {
+    if (fixed_ws) {
+      if (n * sizeof(*ptr) > fixed_bytes)
+        return fail(ctx, ACMPC_E_INVALID, "the allocation-free entry point: a workspace region of %zu bytes is too small for this input (%zu needed)",
+                    fixed_bytes, n * sizeof(*ptr));
+      return ACMPC_OK;
+    }
+    const int rc_ = ensure(ctx, buf, n, zero_new, st);
+    ptr = buf.p;
+    return rc_;
+  };
 
   if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[0], st));
 
@@ -458,16 +524,18 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     }
     if (ctx->profiling) { HIPCHK(ctx, hipEventRecord(ctx->ev[1], st)); HIPCHK(ctx, hipEventRecord(ctx->ev[2], st)); }
   } else {
-    if ((rc = ensure(ctx, ctx->d_prod_carry, (size_t)ctx->p_pad, true, st))) return rc;
-    if ((rc = ensure(ctx, ctx->d_rec_id, (size_t)2 * kMaxWavesTotal))) return rc;
-    if ((rc = ensure(ctx, ctx->d_rec_sum, (size_t)2 * kMaxWavesTotal))) return rc;
-    if (lp.hist_lds && (rc = ensure(ctx, ctx->d_prod_slab, (size_t)lp.blocks * ctx->p_pad))) return rc;
+    if ((rc = need(ctx->d_prod_carry, w.prod_carry, (size_t)ctx->p_pad, kNaProdCarryBytes, true))) return rc;
+    if ((rc = need(ctx->d_rec_id, w.rec_id, (size_t)2 * kMaxWavesTotal, kNaRecBytes, false))) return rc;
+    if ((rc = need(ctx->d_rec_sum, w.rec_sum, (size_t)2 * kMaxWavesTotal, kNaRecBytes, false))) return rc;
+    if (lp.hist_lds && (rc = need(ctx->d_prod_slab, w.prod_slab, (size_t)lp.blocks * ctx->p_pad, kNaProdSlabBytes, false))) return rc;
     // neither product table fits LDS: the line pass gathers prices from global memory and leaves the
     // stock deltas to a pass of their own (rather than one global atomic per line)
     StockPlan sp;
     sp.use = false;
     if (!lp.hist_lds) plan_stock(ctx, n_lines, &sp);
-    if (sp.use && (rc = ensure(ctx, ctx->d_prod_slab, (size_t)sp.n_streams * ctx->p_pad))) return rc;
+    if (fixed_ws && !lp.hist_lds)
+      return fail(ctx, ACMPC_E_INVALID, "the allocation-free entry point needs a product table that fits LDS");
+    if (sp.use && (rc = need(ctx->d_prod_slab, w.prod_slab, (size_t)sp.n_streams * ctx->p_pad, kNaProdSlabBytes, false))) return rc;
 
     LinesArgs a;
     a.order_id = d_order_id; a.product_idx = d_product_idx; a.qty = d_qty;
@@ -483,8 +551,8 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       a.flush_reserve = lp.flush_reserve;
       a.tile_lines = lp.tile_lines;
     }
-    a.order_total = d_tot; a.prod_slab = ctx->d_prod_slab.p; a.prod_carry = ctx->d_prod_carry.p;
-    a.rec_id = ctx->d_rec_id.p; a.rec_sum = ctx->d_rec_sum.p; a.status = ctx->d_status;
+    a.order_total = d_tot; a.prod_slab = w.prod_slab; a.prod_carry = w.prod_carry;
+    a.rec_id = w.rec_id; a.rec_sum = w.rec_sum; a.status = w.status;
     a.line_price = reinterpret_cast<const long long*>(d_line_price);
     a.price_in_lds = lp.price_lds ? 1 : 0;
     a.only_if_unsorted = 0;
@@ -496,7 +564,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.order_state = d_state;
     a.no_hist = sp.use ? 1 : 0;
 
-    ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
+    if (!fixed_ws) ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
     if (any_order) {
       HIPCHK(ctx, hipMemsetAsync(d_tot, 0, (size_t)n_orders * 8, st));
       const size_t tables = !lp.lds_tables ? 0 : (size_t)ctx->p_pad * ((lp.price_lds ? (lp.price32 ? 4 : 8) : 0) + (lp.hist_lds ? 4 : 0));
@@ -533,7 +601,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       k.order_id = d_order_id; k.product_idx = d_product_idx; k.qty = d_qty;
       k.n_lines = n_lines; k.n_tiles = sp.n_tiles; k.tiles_per_stream = sp.tiles_per_stream;
       k.n_products = P; k.p_pad = ctx->p_pad; k.span = sp.span; k.n_ranges = sp.n_ranges; k.n_streams = sp.n_streams;
-      k.q_small = sp.q_small; k.prod_slab = ctx->d_prod_slab.p; k.prod_carry = ctx->d_prod_carry.p;
+      k.q_small = sp.q_small; k.prod_slab = w.prod_slab; k.prod_carry = w.prod_carry;
       k.base = base; k.n_orders = (int32_t)n_orders; k.order_state = d_state;
       if ((rc = set_dyn_lds(ctx, k_stock, sp.lds_bytes))) return rc;
       hipLaunchKernelGGL(k_stock, dim3(sp.blocks), dim3(1024), sp.lds_bytes, st, k);
@@ -541,12 +609,12 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     }
     if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
 
-    f.rec_id = ctx->d_rec_id.p; f.rec_sum = ctx->d_rec_sum.p; f.n_rec = 2 * lp.n_active_waves;
-    f.base = base; f.n_orders = (int32_t)n_orders; f.order_total = d_tot; f.status = ctx->d_status;
-    f.prod_slab = ctx->d_prod_slab.p; f.n_slabs = sp.use ? sp.n_streams : lp.blocks; f.p_pad = ctx->p_pad; f.n_products = P;
+    f.rec_id = w.rec_id; f.rec_sum = w.rec_sum; f.n_rec = 2 * lp.n_active_waves;
+    f.base = base; f.n_orders = (int32_t)n_orders; f.order_total = d_tot; f.status = w.status;
+    f.prod_slab = w.prod_slab; f.n_slabs = sp.use ? sp.n_streams : lp.blocks; f.p_pad = ctx->p_pad; f.n_products = P;
     f.merge_products = (lp.hist_lds || sp.use) ? 1 : 0;
     f.fix_orders = any_order ? 0 : 1;
-    f.prod_carry = ctx->d_prod_carry.p; f.product_qty = d_pq;
+    f.prod_carry = w.prod_carry; f.product_qty = d_pq;
     f.ablate = ctx->ablate_fix;
     f.order_descuento = a.order_descuento; f.descuento_mode = a.descuento_mode;
     if (!fused) {
@@ -556,7 +624,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       HIPCHK(ctx, hipGetLastError());
     }
     if (!f.merge_products) {
-      hipLaunchKernelGGL(k_move_clear, dim3((P + 255) / 256), dim3(256), 0, st, ctx->d_prod_carry.p, d_pq, P);
+      hipLaunchKernelGGL(k_move_clear, dim3((P + 255) / 256), dim3(256), 0, st, w.prod_carry, d_pq, P);
       HIPCHK(ctx, hipGetLastError());
     }
     if (ctx->line_order == ACMPC_ORDER_AUTO) {
@@ -568,7 +636,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       LinesArgs b = a;
       b.n_tiles = ap.n_tiles; b.tiles_per_wave = ap.tiles_per_wave; b.tile_lines = ap.tile_lines;
       b.price_in_lds = ap.price_lds ? 1 : 0; b.only_if_unsorted = 1; b.totals_only = 1;
-      hipLaunchKernelGGL(k_zero_if_unsorted, dim3(ctx->n_cu * 4), dim3(256), 0, st, d_tot, n_orders, ctx->d_status);
+      hipLaunchKernelGGL(k_zero_if_unsorted, dim3(ctx->n_cu * 4), dim3(256), 0, st, d_tot, n_orders, w.status);
       HIPCHK(ctx, hipGetLastError());
       const size_t tables = !ap.lds_tables ? 0 : (size_t)ctx->p_pad * ((ap.price_lds ? (ap.price32 ? 4 : 8) : 0) + (ap.hist_lds ? 4 : 0));
       if (life_lines) {
@@ -580,7 +648,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       else if (ap.price32) rc = launch_lines_any<int32_t, true>(ctx, ap, tables, b, st);
       else rc = launch_lines_any<int64_t, true>(ctx, ap, tables, b, st);
       if (rc) return rc;
-      hipLaunchKernelGGL(k_clear_unsorted, dim3(1), dim3(64), 0, st, ctx->d_status);
+      hipLaunchKernelGGL(k_clear_unsorted, dim3(1), dim3(64), 0, st, w.status);
       HIPCHK(ctx, hipGetLastError());
     }
     if (d_desc && !desc_in_lines) {   // totals are final after k_fixup: take the discounts off
@@ -596,25 +664,23 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     HIPCHK(ctx, hipMemsetAsync(d_ct, 0, (size_t)n_customers * 8, st));
     if (ctx->profiling) { HIPCHK(ctx, hipEventRecord(ctx->ev[3], st)); HIPCHK(ctx, hipEventRecord(ctx->ev[4], st)); }
   } else {
-    if (ctx->d_cust_carry.cap < (size_t)n_customers) {
-      if ((rc = ensure(ctx, ctx->d_cust_carry, (size_t)n_customers, true, st))) return rc;
-    }
-    if (cp.lds_tables && (rc = ensure(ctx, ctx->d_cust_slab, (size_t)cp.n_streams * cp.c_pad))) return rc;
+    if ((rc = need(ctx->d_cust_carry, w.cust_carry, (size_t)n_customers, kNaCustCarryBytes, true))) return rc;
+    if (cp.lds_tables && (rc = need(ctx->d_cust_slab, w.cust_slab, (size_t)cp.n_streams * cp.c_pad, kNaCustSlabBytes, false))) return rc;
     CustArgs c;
     c.order_customer = d_order_customer; c.order_total = d_tot; c.n_orders = n_orders;
     c.n_tiles = cp.n_tiles; c.tiles_per_stream = cp.tiles_per_stream;
     c.n_customers = n_customers; c.c_pad = cp.c_pad; c.span = cp.span; c.n_ranges = cp.n_ranges;
-    c.n_streams = cp.n_streams; c.cust_slab = ctx->d_cust_slab.p; c.cust_carry = ctx->d_cust_carry.p;
-    c.status = ctx->d_status;
+    c.n_streams = cp.n_streams; c.cust_slab = w.cust_slab; c.cust_carry = w.cust_carry;
+    c.status = w.status;
     c.ablate = ctx->ablate_k2;
     c.order_state = d_state;
-    ctx->carry_dirty = true;
+    if (!fixed_ws) ctx->carry_dirty = true;
     if (fused) {
-      if ((rc = ensure(ctx, ctx->d_edge_idx, (size_t)2 * kMaxWavesTotal))) return rc;
-      if ((rc = ensure(ctx, ctx->d_edge_total, (size_t)2 * kMaxWavesTotal))) return rc;
+      if ((rc = need(ctx->d_edge_idx, w.edge_idx, (size_t)2 * kMaxWavesTotal, kNaRecBytes, false))) return rc;
+      if ((rc = need(ctx->d_edge_total, w.edge_total, (size_t)2 * kMaxWavesTotal, kNaRecBytes, false))) return rc;
       f.deferred = 1;
-      f.order_customer = d_order_customer; f.cust_carry = ctx->d_cust_carry.p; f.n_customers = n_customers;
-      f.edge_idx = ctx->d_edge_idx.p; f.edge_total = ctx->d_edge_total.p;
+      f.order_customer = d_order_customer; f.cust_carry = w.cust_carry; f.n_customers = n_customers;
+      f.edge_idx = w.edge_idx; f.edge_total = w.edge_total;
       CustFusedArgs fa;
       fa.c = c;
       fa.f = f;
@@ -638,25 +704,25 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
     if (fused) {
       TailArgs t;
-      t.m.cust_slab = ctx->d_cust_slab.p; t.m.n_streams = cp.n_streams; t.m.c_pad = cp.c_pad;
-      t.m.n_customers = n_customers; t.m.cust_carry = ctx->d_cust_carry.p; t.m.customer_total = d_ct;
+      t.m.cust_slab = w.cust_slab; t.m.n_streams = cp.n_streams; t.m.c_pad = cp.c_pad;
+      t.m.n_customers = n_customers; t.m.cust_carry = w.cust_carry; t.m.customer_total = d_ct;
       t.f = f;
       t.n_cust_blocks = (n_customers + 255) / 256;
       t.n_prod_blocks = 0;          // the leading workgroups of the fused launch merged the stock deltas
       hipLaunchKernelGGL(k_tail, dim3(t.n_cust_blocks + t.n_prod_blocks + (f.n_rec + 255) / 256), dim3(256), 0, st, t);
     } else if (cp.lds_tables) {
       CustMergeArgs m;
-      m.cust_slab = ctx->d_cust_slab.p; m.n_streams = cp.n_streams; m.c_pad = cp.c_pad;
-      m.n_customers = n_customers; m.cust_carry = ctx->d_cust_carry.p; m.customer_total = d_ct;
+      m.cust_slab = w.cust_slab; m.n_streams = cp.n_streams; m.c_pad = cp.c_pad;
+      m.n_customers = n_customers; m.cust_carry = w.cust_carry; m.customer_total = d_ct;
       hipLaunchKernelGGL(k_custmerge, dim3((n_customers + 255) / 256), dim3(256), 0, st, m);
     } else {
       hipLaunchKernelGGL(k_move_clear, dim3((n_customers + 255) / 256), dim3(256), 0, st,
-                         ctx->d_cust_carry.p, d_ct, n_customers);
+                         w.cust_carry, d_ct, n_customers);
     }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
   }
-  ctx->carry_dirty = false;
+  if (!fixed_ws) ctx->carry_dirty = false;
   if (ctx->profiling) ctx->ev_recorded = true;
   return ACMPC_OK;
 }
@@ -738,6 +804,18 @@ ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
   ctx->k2_cus = env_int("ACMPC_K2_CUS", 0);
   if (ctx->k2_threads != 256 && ctx->k2_threads != 512 && ctx->k2_threads != 1024) ctx->k2_threads = 1024;
   ctx->force_global_tables = env_int("ACMPC_FORCE_GLOBAL_TABLES", 0);
+  if (device < kMaxDevices && !g_scratch_ptr[device]) {
+    // `device` is current here.  The array's name is not a device address: this call returns the one the
+    // kernels can use on this device.
+    unsigned char* sp = nullptr;
+    const hipError_t es = hipGetSymbolAddress((void**)&sp, HIP_SYMBOL(scratch));
+    if (es != hipSuccess || !sp) {
+      fail(nullptr, ACMPC_E_HIP, "acmpc_init: hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(es));
+      delete ctx;
+      return ACMPC_E_HIP;
+    }
+    g_scratch_ptr[device] = sp;
+  }
   hipError_t e = hipMalloc((void**)&ctx->d_status, sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemset(ctx->d_status, 0, sizeof(uint32_t));
   for (int i = 0; i <= ACMPC_N_KERNELS && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
@@ -803,6 +881,19 @@ ACMPC_API int acmpc_aggregate_device(acmpc_ctx* ctx, const int32_t* d_order_id, 
   return aggregate_device_impl(ctx, d_order_id, d_product_idx, d_qty, n_lines, d_order_customer, n_orders,
                                order_id_base, n_customers, d_out_order_total_cents, d_out_product_qty,
                                d_out_customer_total_cents, (hipStream_t)hip_stream);
+}
+
+ACMPC_API int acmpc_aggregate_device_noalloc(acmpc_ctx* ctx, const int32_t* d_order_id, const int32_t* d_product_idx,
+                                             const int32_t* d_qty, int64_t n_lines, const int32_t* d_order_customer,
+                                             int64_t n_orders, int32_t order_id_base, int32_t n_customers,
+                                             int64_t* d_out_order_total_cents, int64_t* d_out_product_qty,
+                                             int64_t* d_out_customer_total_cents, void* hip_stream) {
+  if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_aggregate_device_noalloc: null context");
+  unsigned char* ws = ctx->device < kMaxDevices ? g_scratch_ptr[ctx->device] : nullptr;   // set by acmpc_init
+  if (!ws) return fail(ctx, ACMPC_E_STATE, "acmpc_aggregate_device_noalloc: no scratch address for device %d", ctx->device);
+  return aggregate_device_impl(ctx, d_order_id, d_product_idx, d_qty, n_lines, d_order_customer, n_orders,
+                               order_id_base, n_customers, d_out_order_total_cents, d_out_product_qty,
+                               d_out_customer_total_cents, (hipStream_t)hip_stream, nullptr, ws);
 }
 
 ACMPC_API int acmpc_aggregate_lifecycle_device(acmpc_ctx* ctx, const int32_t* d_order_id, const int32_t* d_product_idx,

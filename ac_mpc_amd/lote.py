@@ -155,10 +155,13 @@ class MotorLote:
     # -- device-resident columns (torch tensors on this context's GPU) --------------------------
     def agregar_device(self, order_id, product_idx, qty, order_customer, order_id_base: int, n_customers: int,
                        out_order_total, out_product_qty, out_customer_total, stream: Optional[int] = None,
-                       precio_linea=None, estado_pedido=None, descuento=None, descuento_porcentaje: bool = False
-                       ) -> None:
+                       precio_linea=None, estado_pedido=None, descuento=None, descuento_porcentaje: bool = False,
+                       sin_reservas: bool = False) -> None:
         """Enqueue the aggregation of device-resident columns; outputs are torch int64 CUDA tensors.
         The lifecycle columns (see `agregar`) are torch CUDA tensors of int64 / uint8 / int32.
+        sin_reservas: go through acmpc_aggregate_device_noalloc, which allocates nothing (fixed workspace
+        inside the library, shared by every call on the GPU; grouped rows, no lifecycle columns, sizes
+        within that entry point's limits).
 
         Returns without waiting.  Call `estado()` to wait and check the data contract.
         """
@@ -183,6 +186,14 @@ class MotorLote:
                 raise ErrorLote(_lib.E_INVALID, "longitudes de columnas o resultados incoherentes")
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
+        if sin_reservas:
+            if life is not None:
+                raise ErrorLote(_lib.E_INVALID, "sin_reservas no admite columnas de ciclo de vida")
+            self._check(self._lib.acmpc_aggregate_device_noalloc(
+                self._ctx, order_id.data_ptr(), product_idx.data_ptr(), qty.data_ptr(), n,
+                order_customer.data_ptr(), m, int(order_id_base), int(n_customers),
+                out_order_total.data_ptr(), out_product_qty.data_ptr(), out_customer_total.data_ptr(), stream))
+            return
         self._check(self._lib.acmpc_aggregate_lifecycle_device(
             self._ctx, order_id.data_ptr(), product_idx.data_ptr(), qty.data_ptr(), n,
             order_customer.data_ptr(), m, int(order_id_base), int(n_customers),

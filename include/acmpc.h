@@ -145,6 +145,30 @@ int acmpc_aggregate_device(acmpc_ctx* ctx,
                            void* hip_stream);
 
 /*
+ * acmpc_aggregate_device for callers that cannot allocate device memory while they call it: code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in
+ * the reference.  Same arguments, same results bit for bit; the call itself allocates and frees
+ * nothing.  Its workspace (per-workgroup stock-delta and per-stream customer partials, 64-bit carry
+ * cells, the records of orders cut by wave boundaries) is a fixed 61.4 MiB array inside the library's
+ * code object, of which every GPU the library runs on holds its own copy until the process ends.
+ * Limits (ACMPC_E_INVALID beyond them, with the limit in acmpc_last_error): at most 16380 products
+ * whose tables fit LDS (about 14.7 k with prices below 2^31 cents, 9.8 k otherwise) and at most
+ * 131072 customers; ACMPC_ORDER_GROUPED only, no lifecycle columns.  acmpc_set_products must have been
+ * called before (it is the call that allocates the price table).
+ * Every call on one GPU, from any context of the process, uses that GPU's one array: calls that
+ * overlap in time on one GPU race, also on different streams or contexts.  Serialise them.
+ */
+int acmpc_aggregate_device_noalloc(acmpc_ctx* ctx,
+                                   const int32_t* d_order_id, const int32_t* d_product_idx,
+                                   const int32_t* d_qty, int64_t n_lines,
+                                   const int32_t* d_order_customer, int64_t n_orders,
+                                   int32_t order_id_base, int32_t n_customers,
+                                   int64_t* d_out_order_total_cents,
+                                   int64_t* d_out_product_qty,
+                                   int64_t* d_out_customer_total_cents,
+                                   void* hip_stream);
+
+/*
  * Order lifecycle: optional columns that make the sums right over time, not only for a frozen
  * snapshot of the tables.  Every pointer may be NULL (= the column is absent).
  *
