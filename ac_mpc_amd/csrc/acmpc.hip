@@ -3,6 +3,7 @@
 #include "acmpc_kernels.hpp"
 #include "acmpc_ingest.hpp"
 #include "acmpc_emit.hpp"
+#include "acmpc_comm.hpp"
 #include "../../include/acmpc.h"
 
 #include <algorithm>
@@ -91,6 +92,7 @@ struct acmpc_ctx {
   // staging buffers of the host-pointer entry point
   DevBuf<int32_t> s_order_id, s_product_idx, s_qty, s_order_customer;
   DevBuf<int64_t> s_order_total, s_product_qty, s_customer_total;
+  DevBuf<int64_t> s_merged;        // [product_qty | customer_total_cents] of the sharded host entry point
   DevBuf<int64_t> s_line_price;
   DevBuf<unsigned char> s_order_state;
   DevBuf<int32_t> s_order_descuento;
@@ -836,7 +838,7 @@ ACMPC_API void acmpc_destroy(acmpc_ctx* ctx) {
   release(ctx->d_price); release(ctx->d_prod_slab); release(ctx->d_prod_carry);
   release(ctx->d_rec_id); release(ctx->d_rec_sum); release(ctx->d_cust_slab); release(ctx->d_cust_carry);
   release(ctx->s_order_id); release(ctx->s_product_idx); release(ctx->s_qty); release(ctx->s_order_customer);
-  release(ctx->s_order_total); release(ctx->s_product_qty); release(ctx->s_customer_total);
+  release(ctx->s_order_total); release(ctx->s_product_qty); release(ctx->s_customer_total); release(ctx->s_merged);
   release(ctx->s_synth_off); release(ctx->s_synth_cdf);
   release(ctx->d_edge_idx); release(ctx->d_edge_total);
   release(ctx->d_dict); release(ctx->d_dict_disp); release(ctx->d_codes); release(ctx->d_chunk_rows); release(ctx->d_ing_tables);
@@ -1472,4 +1474,232 @@ ACMPC_API int acmpc_emit_stock(acmpc_ctx* ctx, const int64_t* product_qty, int32
   if (n_products < 0) return fail(ctx, ACMPC_E_INVALID, "acmpc_emit_stock: negative size");
   return emit_host_impl(ctx, "acmpc_emit_stock", kEmitStock, product_qty, n_products, 0, style, text, capacity_bytes,
                         n_bytes);
+}
+
+// ---- multi-GPU: shards by order-id range, one all-reduce ---------------------------------------
+
+namespace {
+
+#define NCCLCHK(ctx, api, call)                                                                \
+  do {                                                                                         \
+    ncclResult_t r_ = (call);                                                                  \
+    if (r_ != ncclSuccess)                                                                     \
+      return fail(ctx, ACMPC_E_HIP, "%s failed: %s", #call, (api)->GetErrorString(r_));        \
+  } while (0)
+
+const RcclApi* need_rccl(acmpc_ctx* ctx, int* rc) {
+  const char* why = "";
+  const RcclApi* api = rccl_api(&why);
+  if (!api) *rc = fail(ctx, ACMPC_E_STATE, "RCCL is not available: %s", why);
+  return api;
+}
+
+}  // namespace
+
+ACMPC_API int acmpc_comm_id(char* id128) {
+  if (!id128) return fail(nullptr, ACMPC_E_INVALID, "acmpc_comm_id: null buffer");
+  int rc = 0;
+  const RcclApi* api = need_rccl(nullptr, &rc);
+  if (!api) return rc;
+  static_assert(sizeof(ncclUniqueId) == ACMPC_COMM_ID_BYTES, "the id travels as ACMPC_COMM_ID_BYTES opaque bytes");
+  ncclUniqueId id;
+  NCCLCHK(nullptr, api, api->GetUniqueId(&id));
+  memcpy(id128, &id, sizeof(id));
+  return ACMPC_OK;
+}
+
+ACMPC_API int acmpc_comm_init_rank(acmpc_comm** out, acmpc_ctx* ctx, const char* id128, int rank, int world) {
+  if (!out) return fail(ctx, ACMPC_E_INVALID, "acmpc_comm_init_rank: null out pointer");
+  *out = nullptr;
+  if (!ctx || !id128 || world <= 0 || rank < 0 || rank >= world)
+    return fail(ctx, ACMPC_E_INVALID, "acmpc_comm_init_rank: bad argument (rank %d of %d)", rank, world);
+  int rc = 0;
+  const RcclApi* api = need_rccl(ctx, &rc);
+  if (!api) return rc;
+  ENTER_DEVICE(ctx);                                   // a communicator rank belongs to the current device
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  acmpc_comm* c = new (std::nothrow) acmpc_comm();
+  if (!c) return fail(ctx, ACMPC_E_NOMEM, "acmpc_comm_init_rank: out of host memory");
+  const ncclResult_t r = api->CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) {
+    delete c;
+    return fail(ctx, ACMPC_E_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, api->GetErrorString(r));
+  }
+  c->device = ctx->device; c->rank = rank; c->world = world;
+  *out = c;
+  return ACMPC_OK;
+}
+
+ACMPC_API int acmpc_comm_init_all(acmpc_comm** out, acmpc_ctx* const* ctxs, int n_devices) {
+  if (!out || !ctxs || n_devices <= 0 || n_devices > kMaxDevices)
+    return fail(nullptr, ACMPC_E_INVALID, "acmpc_comm_init_all: bad argument");
+  for (int g = 0; g < n_devices; ++g) out[g] = nullptr;
+  for (int g = 0; g < n_devices; ++g) {
+    if (!ctxs[g]) return fail(nullptr, ACMPC_E_INVALID, "acmpc_comm_init_all: null context %d", g);
+    for (int h = 0; h < g; ++h)
+      if (ctxs[h]->device == ctxs[g]->device)
+        return fail(ctxs[0], ACMPC_E_INVALID, "acmpc_comm_init_all: contexts %d and %d share device %d", h, g, ctxs[g]->device);
+  }
+  acmpc_ctx* ctx0 = ctxs[0];
+  int rc = 0;
+  const RcclApi* api = need_rccl(ctx0, &rc);
+  if (!api) return rc;
+  return guarded(ctx0, "acmpc_comm_init_all", [&]() -> int {
+    std::vector<int> devs(n_devices);
+    std::vector<ncclComm_t> comms(n_devices, nullptr);
+    for (int g = 0; g < n_devices; ++g) devs[g] = ctxs[g]->device;
+    DeviceScope keep;                                  // ncclCommInitAll moves the current device about
+    HIPCHK(ctx0, keep.enter(ctx0->device));
+    NCCLCHK(ctx0, api, api->CommInitAll(comms.data(), n_devices, devs.data()));
+    (void)hipSetDevice(ctx0->device);
+    for (int g = 0; g < n_devices; ++g) {
+      acmpc_comm* c = new acmpc_comm();
+      c->comm = comms[g]; c->device = devs[g]; c->rank = g; c->world = n_devices;
+      out[g] = c;
+    }
+    return ACMPC_OK;
+  });
+}
+
+ACMPC_API void acmpc_comm_destroy(acmpc_comm* comm) {
+  if (!comm) return;
+  const RcclApi* api = rccl_api(nullptr);
+  if (api && comm->comm) {
+    DeviceScope scope;
+    (void)scope.enter(comm->device);
+    (void)api->CommDestroy(comm->comm);
+  }
+  delete comm;
+}
+
+ACMPC_API int acmpc_merge_device(acmpc_ctx* ctx, acmpc_comm* comm, int64_t* d_values, int64_t count, void* hip_stream) {
+  if (!ctx || !comm || count < 0 || (count > 0 && !d_values))
+    return fail(ctx, ACMPC_E_INVALID, "acmpc_merge_device: bad argument");
+  if (comm->device != ctx->device)
+    return fail(ctx, ACMPC_E_INVALID, "acmpc_merge_device: the communicator rank lives on device %d, the context on %d",
+                comm->device, ctx->device);
+  if (count == 0) return ACMPC_OK;
+  int rc = 0;
+  const RcclApi* api = need_rccl(ctx, &rc);
+  if (!api) return rc;
+  ENTER_DEVICE(ctx);
+  NCCLCHK(ctx, api, api->AllReduce(d_values, d_values, (size_t)count, ncclInt64, ncclSum, comm->comm, (hipStream_t)hip_stream));
+  return ACMPC_OK;
+}
+
+ACMPC_API int acmpc_merge_group_device(acmpc_ctx* const* ctxs, acmpc_comm* const* comms, int n_devices,
+                                       int64_t* const* d_values, int64_t count, void* const* hip_streams) {
+  if (!ctxs || !comms || !d_values || n_devices <= 0 || count < 0)
+    return fail(nullptr, ACMPC_E_INVALID, "acmpc_merge_group_device: bad argument");
+  for (int g = 0; g < n_devices; ++g)
+    if (!ctxs[g] || !comms[g] || (count > 0 && !d_values[g]) || comms[g]->device != ctxs[g]->device)
+      return fail(ctxs[0], ACMPC_E_INVALID, "acmpc_merge_group_device: bad context, communicator or buffer %d", g);
+  if (count == 0) return ACMPC_OK;
+  acmpc_ctx* ctx0 = ctxs[0];
+  int rc = 0;
+  const RcclApi* api = need_rccl(ctx0, &rc);
+  if (!api) return rc;
+  // one thread drives every rank: the calls must sit in one group, or the first would wait for the others
+  NCCLCHK(ctx0, api, api->GroupStart());
+  ncclResult_t first_bad = ncclSuccess;
+  for (int g = 0; g < n_devices; ++g) {
+    const ncclResult_t r = api->AllReduce(d_values[g], d_values[g], (size_t)count, ncclInt64, ncclSum, comms[g]->comm,
+                                          hip_streams ? (hipStream_t)hip_streams[g] : nullptr);
+    if (r != ncclSuccess && first_bad == ncclSuccess) first_bad = r;
+  }
+  const ncclResult_t rend = api->GroupEnd();
+  if (first_bad != ncclSuccess) return fail(ctx0, ACMPC_E_HIP, "ncclAllReduce failed: %s", api->GetErrorString(first_bad));
+  if (rend != ncclSuccess) return fail(ctx0, ACMPC_E_HIP, "ncclGroupEnd failed: %s", api->GetErrorString(rend));
+  return ACMPC_OK;
+}
+
+ACMPC_API int acmpc_aggregate_sharded(acmpc_ctx* const* ctxs, acmpc_comm* const* comms, int n_devices,
+                                      const int32_t* order_id, const int32_t* product_idx, const int32_t* qty,
+                                      int64_t n_lines, const int32_t* order_customer, int64_t n_orders,
+                                      int32_t order_id_base, int32_t n_customers, int64_t* out_order_total_cents,
+                                      int64_t* out_product_qty, int64_t* out_customer_total_cents) {
+  if (!ctxs || !comms || n_devices <= 0 || n_devices > kMaxDevices)
+    return fail(nullptr, ACMPC_E_INVALID, "acmpc_aggregate_sharded: bad device list");
+  for (int g = 0; g < n_devices; ++g)
+    if (!ctxs[g] || !comms[g] || comms[g]->device != ctxs[g]->device || comms[g]->world != n_devices)
+      return fail(ctxs[0], ACMPC_E_INVALID, "acmpc_aggregate_sharded: bad context or communicator %d", g);
+  acmpc_ctx* ctx0 = ctxs[0];
+  const int32_t P = ctx0->n_products;
+  if (P <= 0) return fail(ctx0, ACMPC_E_STATE, "acmpc_set_products has not been called");
+  for (int g = 1; g < n_devices; ++g)
+    if (ctxs[g]->n_products != P)
+      return fail(ctx0, ACMPC_E_STATE, "acmpc_aggregate_sharded: context %d holds %d products, context 0 holds %d", g,
+                  ctxs[g]->n_products, P);
+  if (n_lines < 0 || n_orders < 0 || n_customers <= 0) return fail(ctx0, ACMPC_E_INVALID, "negative size or n_customers <= 0");
+  if (n_orders > 0x7fffffffll || n_lines > (1ll << 40) || n_customers > kMaxCustomers)
+    return fail(ctx0, ACMPC_E_INVALID, "size beyond the limits (n_orders int32, n_lines 2^40, n_customers %d)", kMaxCustomers);
+  if ((n_lines > 0 && (!order_id || !product_idx || !qty)) || (n_orders > 0 && (!order_customer || !out_order_total_cents)) ||
+      !out_product_qty || !out_customer_total_cents)
+    return fail(ctx0, ACMPC_E_INVALID, "null host pointer");
+  if (n_lines > 0 && n_orders == 0) return fail(ctx0, ACMPC_E_INVALID, "n_lines > 0 with n_orders == 0");
+  const int64_t n_merged = (int64_t)P + n_customers;
+  DeviceScope keep;                                    // the loop below moves the current device about
+  HIPCHK(ctx0, keep.enter(ctx0->device));
+  // Shard g owns the order indices [floor(g*M/G), floor((g+1)*M/G)) and exactly their lines: the cut in
+  // the line columns is the first line whose id reaches the shard's first order (the ids ascend).
+  int64_t o_cut[kMaxDevices + 1], l_cut[kMaxDevices + 1];
+  for (int g = 0; g <= n_devices; ++g) {
+    o_cut[g] = (int64_t)(((__int128)n_orders * g) / n_devices);
+    const int64_t first_id = (int64_t)order_id_base + o_cut[g];
+    l_cut[g] = g == n_devices ? n_lines
+                              : std::lower_bound(order_id, order_id + n_lines, first_id,
+                                                 [](int32_t a, int64_t b) { return (int64_t)a < b; }) - order_id;
+  }
+  l_cut[0] = 0;                                        // ids below the base stay with shard 0, which reports them
+  int rc;
+  for (int g = 0; g < n_devices; ++g) {
+    acmpc_ctx* c = ctxs[g];
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t nl = l_cut[g + 1] - l_cut[g], no = o_cut[g + 1] - o_cut[g];
+    if ((rc = ensure(c, c->s_order_id, (size_t)nl))) return rc;
+    if ((rc = ensure(c, c->s_product_idx, (size_t)nl))) return rc;
+    if ((rc = ensure(c, c->s_qty, (size_t)nl))) return rc;
+    if ((rc = ensure(c, c->s_order_customer, (size_t)no))) return rc;
+    if ((rc = ensure(c, c->s_order_total, (size_t)no))) return rc;
+    if ((rc = ensure(c, c->s_merged, (size_t)n_merged))) return rc;
+    hipStream_t st = nullptr;
+    HIPCHK(c, hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), st));
+    if (nl > 0) {
+      HIPCHK(c, hipMemcpyAsync(c->s_order_id.p, order_id + l_cut[g], (size_t)nl * 4, hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(c->s_product_idx.p, product_idx + l_cut[g], (size_t)nl * 4, hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(c->s_qty.p, qty + l_cut[g], (size_t)nl * 4, hipMemcpyHostToDevice, st));
+    }
+    if (no > 0) HIPCHK(c, hipMemcpyAsync(c->s_order_customer.p, order_customer + o_cut[g], (size_t)no * 4, hipMemcpyHostToDevice, st));
+    rc = aggregate_device_impl(c, c->s_order_id.p, c->s_product_idx.p, c->s_qty.p, nl, c->s_order_customer.p, no,
+                               (int32_t)((int64_t)order_id_base + o_cut[g]), n_customers, c->s_order_total.p, c->s_merged.p,
+                               c->s_merged.p + P, st);
+    if (rc) { if (c != ctx0) fail(ctx0, rc, "shard %d: %s", g, c->err); return rc; }
+  }
+  // the one exchange: [product_qty | customer_total_cents], summed in place on every device
+  {
+    int64_t* bufs[kMaxDevices];
+    for (int g = 0; g < n_devices; ++g) bufs[g] = ctxs[g]->s_merged.p;
+    if ((rc = acmpc_merge_group_device(ctxs, comms, n_devices, bufs, n_merged, nullptr))) return rc;
+  }
+  for (int g = 0; g < n_devices; ++g) {
+    acmpc_ctx* c = ctxs[g];
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t no = o_cut[g + 1] - o_cut[g];
+    if (no > 0)
+      HIPCHK(c, hipMemcpyAsync(out_order_total_cents + o_cut[g], c->s_order_total.p, (size_t)no * 8, hipMemcpyDeviceToHost, nullptr));
+    if (g == 0) {
+      HIPCHK(c, hipMemcpyAsync(out_product_qty, c->s_merged.p, (size_t)P * 8, hipMemcpyDeviceToHost, nullptr));
+      HIPCHK(c, hipMemcpyAsync(out_customer_total_cents, c->s_merged.p + P, (size_t)n_customers * 8, hipMemcpyDeviceToHost, nullptr));
+    }
+  }
+  uint32_t all = 0;
+  int worst = ACMPC_OK;
+  for (int g = 0; g < n_devices; ++g) {
+    uint32_t flags = 0;
+    const int r = acmpc_status(ctxs[g], nullptr, &flags);   // waits for the device, collects its verdict on the data
+    all |= flags;
+    if (r != ACMPC_OK && worst == ACMPC_OK) { worst = r; if (ctxs[g] != ctx0) fail(ctx0, r, "shard %d: %s", g, ctxs[g]->err); }
+  }
+  return worst;
 }

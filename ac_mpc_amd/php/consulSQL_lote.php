@@ -53,7 +53,21 @@ class consultasLote {
                             char* text, int64_t capacity_bytes, int64_t* n_bytes);
         int acmpc_host_alloc(acmpc_ctx* ctx, int64_t n_bytes, void** out);
         int acmpc_host_free(acmpc_ctx* ctx, void* p);
+        typedef struct acmpc_comm acmpc_comm;
+        int acmpc_comm_init_all(acmpc_comm** out, acmpc_ctx* const* ctxs, int n_devices);
+        void acmpc_comm_destroy(acmpc_comm* comm);
+        int acmpc_aggregate_sharded(acmpc_ctx* const* ctxs, acmpc_comm* const* comms, int n_devices,
+                            const int32_t* order_id, const int32_t* product_idx, const int32_t* qty, int64_t n_lines,
+                            const int32_t* order_customer, int64_t n_orders,
+                            int32_t order_id_base, int32_t n_customers,
+                            int64_t* out_order_total_cents, int64_t* out_product_qty,
+                            int64_t* out_customer_total_cents);
     ";
+
+    /* Every GPU of the node: contexts [0] = the one of conectar(), communicator ranks beside them. */
+    private static $ctxs = null;
+    private static $coms = null;
+    private static $nGpus = 1;
 
     /* Counterpart of ejecutarSQL::conectar() (library/consulSQL.php:5-16). */
     public static function conectar($lib = "libacmpc.so", $device = 0) {
@@ -100,6 +114,8 @@ class consultasLote {
         self::conectar();
         $p = self::columna("int64_t", $preciosCentavos);
         self::comprobar(self::$ffi->acmpc_set_products(self::$ctx, $p, count($preciosCentavos)), "cargar productos");
+        for ($g = 1; self::$ctxs !== null && $g < self::$nGpus; $g++)      // every GPU holds the same table
+            self::comprobar(self::$ffi->acmpc_set_products(self::$ctxs[$g], $p, count($preciosCentavos)), "cargar productos");
         self::$nProductos = count($preciosCentavos);
     }
 
@@ -122,6 +138,52 @@ class consultasLote {
         $ct  = self::$ffi->new("int64_t[" . max($nClientes, 1) . "]");
         self::comprobar(self::$ffi->acmpc_aggregate(self::$ctx, $oid, $pid, $qty, $n, $cus, $m,
                                                     $primerPedido, $nClientes, $tot, $pq, $ct), "agregar el lote");
+        $TotalPagar = []; $DeltaStock = []; $TotalCliente = [];
+        for ($i = 0; $i < $m; $i++) $TotalPagar[] = $tot[$i];
+        for ($i = 0; $i < self::$nProductos; $i++) $DeltaStock[] = $pq[$i];
+        for ($i = 0; $i < $nClientes; $i++) $TotalCliente[] = $ct[$i];
+        return [$TotalPagar, $DeltaStock, $TotalCliente];
+    }
+
+    /*
+     * One context and one RCCL communicator rank per GPU, all in this process: where the reference
+     * opens one connection per statement (ejecutarSQL::conectar, library/consulSQL.php:5-16), a worker
+     * opens the node's GPUs once.  Call before CargarProductos (the price table goes to every GPU).
+     */
+    public static function conectarTodas($nGpus, $lib = "libacmpc.so") {
+        self::conectar($lib, 0);
+        self::$ctxs = self::$ffi->new("acmpc_ctx*[$nGpus]");
+        self::$coms = self::$ffi->new("acmpc_comm*[$nGpus]");
+        self::$ctxs[0] = self::$ctx;
+        for ($g = 1; $g < $nGpus; $g++) {
+            $out = self::$ffi->new("acmpc_ctx*");
+            $rc = self::$ffi->acmpc_init(FFI::addr($out), $g);
+            if ($rc != 0) die("Error en el servidor, verifique sus datos: " . FFI::string(self::$ffi->acmpc_last_error(null)));
+            self::$ctxs[$g] = $out;
+        }
+        self::comprobar(self::$ffi->acmpc_comm_init_all(self::$coms, self::$ctxs, $nGpus), "abrir el comunicador");
+        self::$nGpus = $nGpus;
+    }
+
+    /*
+     * AgregarDetalle over every GPU opened by conectarTodas: orders are cut into contiguous NumPedido
+     * ranges, one per GPU, and the stock deltas and customer totals are merged by one all-reduce.
+     * Same arguments and results as AgregarDetalle.
+     */
+    public static function AgregarDetalleRepartido($NumPedido, $IndiceProd, $Cantidad, $ClientePorPedido, $primerPedido, $nClientes) {
+        if (self::$ctxs === null) die("Problemas al agregar el lote: conectarTodas no se ha llamado");
+        $n = count($NumPedido);
+        $m = count($ClientePorPedido);
+        $oid = self::columna("int32_t", $NumPedido);
+        $pid = self::columna("int32_t", $IndiceProd);
+        $qty = self::columna("int32_t", $Cantidad);
+        $cus = self::columna("int32_t", $ClientePorPedido);
+        $tot = self::$ffi->new("int64_t[" . max($m, 1) . "]");
+        $pq  = self::$ffi->new("int64_t[" . max(self::$nProductos, 1) . "]");
+        $ct  = self::$ffi->new("int64_t[" . max($nClientes, 1) . "]");
+        self::comprobar(self::$ffi->acmpc_aggregate_sharded(self::$ctxs, self::$coms, self::$nGpus, $oid, $pid, $qty, $n,
+                                                            $cus, $m, $primerPedido, $nClientes, $tot, $pq, $ct),
+                        "agregar el lote repartido");
         $TotalPagar = []; $DeltaStock = []; $TotalCliente = [];
         for ($i = 0; $i < $m; $i++) $TotalPagar[] = $tot[$i];
         for ($i = 0; $i < self::$nProductos; $i++) $DeltaStock[] = $pq[$i];
@@ -191,6 +253,9 @@ class consultasLote {
     }
 
     public static function desconectar() {
+        for ($g = 0; self::$coms !== null && $g < self::$nGpus; $g++) self::$ffi->acmpc_comm_destroy(self::$coms[$g]);
+        for ($g = 1; self::$ctxs !== null && $g < self::$nGpus; $g++) self::$ffi->acmpc_destroy(self::$ctxs[$g]);
+        self::$coms = null; self::$ctxs = null; self::$nGpus = 1;
         if (self::$ctx !== null) self::$ffi->acmpc_destroy(self::$ctx);
         self::$ctx = null;
     }

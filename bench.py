@@ -24,31 +24,113 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E vendor peak (8 TB/s)
-# What this part delivers to a kernel that does nothing but move k_lines' bytes with k_lines' address
-# mapping (tools/stream_probe.hip: three columns read with streaming loads and one 8-byte store per four
-# lines, 0.257 ms for 1.4 GB).  Quoted beside the vendor peak; never used as `peak`.
-ACHIEVABLE_SAME_TRAFFIC_GBS = 5450.0
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=400)     # about 0.15 s of GPU time: long enough to be seen by samplers
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--lines-per-gpu", type=int, default=100_000_000)
     ap.add_argument("--products", type=int, default=10_000)
     ap.add_argument("--customers", type=int, default=100_000)
     ap.add_argument("--zipf", type=int, default=0, help="1: Zipf(s=1) product popularity")
+    ap.add_argument("--shard-of", type=str, default="",
+                    help="R/W with --gpus 1: this GPU holds shard R of W of the set of W x lines-per-gpu lines, at its "
+                         "true global offsets (the per-GPU shape of the sharded 1 B-line configurations); no exchange")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
 def host_threads() -> int:
-    """Threads for the CPU baseline: the box's CPU share (its *_NUM_THREADS setting), never the whole machine."""
+    """Threads for the CPU baseline: the CPUs this process may run on, capped by the box's CPU share
+    (its *_NUM_THREADS setting) when one is set; never more than the machine has."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = os.cpu_count() or 1
     share = os.environ.get("OMP_NUM_THREADS", "")
-    n = int(share) if share.isdigit() and int(share) > 0 else 16
-    return max(1, min(n, os.cpu_count() or 1))
+    if share.isdigit() and int(share) > 0:
+        allowed = min(allowed, int(share))
+    return max(1, min(allowed, os.cpu_count() or 1))
+
+
+def copy_rate_gbs(dev, n_bytes: int = 1 << 30) -> float:
+    """What the part delivers, in this run, to a plain device-to-device copy of `n_bytes` (torch's copy
+    kernel): GB/s over the bytes read plus the bytes written, best of a few repetitions.  The yardstick
+    beside the vendor peak; never used as `peak`."""
+    import torch
+    src = torch.empty(n_bytes // 8, dtype=torch.int64, device=dev)
+    dst = torch.empty_like(src)
+    src.random_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = float("inf")
+    for _ in range(8):
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del src, dst
+    return 2.0 * n_bytes / (best * 1e-3) / 1e9
+
+
+def kernel_source_digest() -> str:
+    """sha256 over the device and host sources of libacmpc.so: a traffic record collected with other
+    kernels than the ones that run now must not be quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "ac_mpc_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def comunicador_capi(motor, rank: int, world: int, dist, timeout_s: float = 120.0):
+    """The library's own RCCL communicator for this rank, or None (on every rank alike) when some rank
+    cannot load RCCL or does not get through ncclCommInitRank in time; the caller then falls back to
+    torch.distributed for the one all-reduce."""
+    import threading
+    import torch
+    from ac_mpc_amd import reparto
+    dev = torch.device("cuda", motor.device)
+
+    def everyone(ok: bool) -> bool:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    ident, ok = None, True
+    try:
+        ident = reparto.nuevo_id()            # every rank: proves that RCCL loads here; only rank 0's id is used
+    except Exception as e:                    # noqa: BLE001
+        print(f"[bench] rank {rank}: {e}", file=sys.stderr, flush=True)
+        ok = False
+    if not everyone(ok):
+        return None
+    box = [ident]
+    dist.broadcast_object_list(box, src=0)
+    got = {}
+
+    def join():
+        try:
+            got["com"] = reparto.ComunicadorC(motor, rank, world, box[0])
+        except Exception as e:                # noqa: BLE001
+            got["err"] = e
+
+    th = threading.Thread(target=join, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    ok = "com" in got
+    if not ok:
+        print(f"[bench] rank {rank}: acmpc_comm_init_rank {'timed out' if th.is_alive() else got.get('err')}",
+              file=sys.stderr, flush=True)
+    if not everyone(ok):
+        return None
+    return got["com"]
 
 
 def cpu_baseline(ds, seconds: float):
@@ -89,7 +171,8 @@ def cpu_baseline(ds, seconds: float):
         many, reps, el = one, 0, 0.0
     else:
         many, reps, el = rate(cores, seconds)
-    return {"value": max(many, one), "unit": "order lines/s", "cores": cores if many >= one else 1, "kind": "port",
+    return {"value": max(many, one), "unit": "order lines/s", "cores": cores if many >= one else 1,
+            "host_cpus": os.cpu_count(), "kind": "port",
             "sample": f"first {n_s} lines ({m_s} orders) of the same columns; {reps} passes of the C oracle on "
                       f"{cores} threads in {el:.1f} s; one thread: {one / 1e9:.2f} G lines/s"}
 
@@ -121,8 +204,14 @@ def main():
 
     motor = MotorLote(local_rank)
     n_total = args.lines_per_gpu * world
+    gen_rank, gen_world = rank, world
+    if args.shard_of:
+        if world != 1:
+            raise SystemExit("--shard-of is for --gpus 1")
+        gen_rank, gen_world = (int(x) for x in args.shard_of.split("/"))
+        n_total = args.lines_per_gpu * gen_world
     ds = sintetico.generar(motor, n_total, args.products, args.customers, zipf=bool(args.zipf), qty_mode=0,
-                           rank=rank, world=world)
+                           rank=gen_rank, world=gen_world)
     dev = ds.order_id.device
     P, Cn = args.products, args.customers
     tot = torch.empty(ds.n_orders, dtype=torch.int64, device=dev)
@@ -131,7 +220,17 @@ def main():
     # (ACMPC_BENCH_OVERLAP=0: one buffer, the all-reduce waited for inside the step).
     overlap = world > 1 and backend == "nccl" and os.environ.get("ACMPC_BENCH_OVERLAP", "1") != "0"
     bufs = [torch.empty(P + Cn, dtype=torch.int64, device=dev) for _ in range(2 if overlap else 1)]
-    turnos = reparto.FusionEnCurso(bufs) if overlap else None
+    # The exchange is issued by the library itself (ncclAllReduce behind the C ABI, the route a PHP host
+    # has); ACMPC_BENCH_MERGE=torch, or a rank that cannot join, puts it back in torch.distributed.
+    com = None
+    if world > 1 and backend == "nccl" and os.environ.get("ACMPC_BENCH_MERGE", "capi") == "capi":
+        com = comunicador_capi(motor, rank, world, dist)
+    merge_path = "none (one GPU)" if world == 1 else \
+        "ncclAllReduce inside libacmpc.so (acmpc_merge_device)" if com else f"torch.distributed all_reduce ({backend})"
+    if overlap:
+        turnos = reparto.FusionEnCursoC(bufs, com) if com else reparto.FusionEnCurso(bufs)
+    else:
+        turnos = None
     merged = bufs[0]
 
     def step():
@@ -141,7 +240,9 @@ def main():
         if overlap:
             turnos.lanzar()
         elif world > 1:
-            if backend == "nccl":
+            if com:
+                com.fusionar(merged)
+            elif backend == "nccl":
                 reparto.fusionar(merged)
             else:
                 host = merged.cpu()
@@ -175,7 +276,9 @@ def main():
     last = turnos.esperar() if overlap else merged
     pq, ct = last[:P], last[P:]
     total_qty = int(pq.sum().item())
-    assert total_qty == n_total, (total_qty, n_total)
+    lines_per_step = ds.n_lines if args.shard_of else n_total        # what all ranks process in one step
+    orders_per_step = ds.n_orders if args.shard_of else ds.n_orders_total
+    assert total_qty == lines_per_step, (total_qty, lines_per_step)
 
     # roofline of the dominant kernel (the order-line pass), from HIP events recorded by the library on
     # the stream the kernels run on
@@ -192,21 +295,31 @@ def main():
     # one int64 price read and one stock-delta partial written per product
     b_lines = 12 * ds.n_lines + 8 * ds.n_orders + 16 * P
     achieved = b_lines / (k_ms["lines"] * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch from the PMC counters: collected by separate rocprofv3 --pmc passes
+    # (tools/profile_gpu.sh) and kept in profiles/pmc_traffic.json with a digest of the sources they were
+    # collected with; a record of other kernels than the ones that ran just now is not quoted.
+    traffic, traffic_note = None, "no PMC record for this workload"
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            rec = json.load(open(tpath))
-            key = f"lines={ds.n_lines},zipf={args.zipf}"
-            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+            rec = json.load(open(tpath)).get(f"lines={ds.n_lines},zipf={args.zipf}")
+            if rec:
+                if rec.get("source_digest") == kernel_source_digest():
+                    traffic, traffic_note = rec.get("hbm_bytes_per_launch"), rec.get("source", "")
+                else:
+                    traffic_note = (f"PMC record is of sources {rec.get('source_digest')}, these are "
+                                    f"{kernel_source_digest()}: not quoted")
+        except Exception as e:                    # noqa: BLE001
+            traffic_note = f"unreadable PMC record: {e}"
+    copy_gbs = copy_rate_gbs(dev) if rank == 0 else 0.0
+    b_step = 12 * ds.n_lines + 12 * ds.n_orders + 16 * P + 8 * Cn       # whole step, this GPU
+    step_ms_device = sum(k_ms.values())
 
     if rank == 0:
         wg, wv = motor.geometria_lineas()
         out = {
             "metric": "order lines aggregated/sec (store.sql schema)",
-            "value": n_total * args.steps / elapsed,
+            "value": lines_per_step * args.steps / elapsed,
             "unit": "order lines/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -218,24 +331,33 @@ def main():
             "dtype": "int64",
             "data": "synthetic",
             "config": {
-                "workload": ("BASELINE configs[2]: 100M order lines, per-order totals + per-product stock decrement "
+                "workload": (f"shard {gen_rank} of {gen_world} of a {n_total}-line set at its global offsets, on one GPU "
+                             f"(per-GPU shape of BASELINE configs[{4 if args.zipf else 3}]), no exchange" if args.shard_of else
+                             "BASELINE configs[2]: 100M order lines, per-order totals + per-product stock decrement "
                              "(+ per-customer totals), single GPU" if world == 1 and args.lines_per_gpu == 100_000_000 else
                              f"{n_total} order lines sharded by order-id range over {world} GPU(s), one all-reduce"),
                 "lines_per_gpu": args.lines_per_gpu, "lines_total": n_total, "orders_total": ds.n_orders_total,
+                "lines_this_gpu": ds.n_lines, "orders_this_gpu": ds.n_orders,
                 "products": P, "customers": Cn, "product_popularity": "zipf(s=1)" if args.zipf else "uniform",
                 "sharding": f"order-id range x{world}" if world > 1 else "none",
-                "orders_per_sec": ds.n_orders_total * args.steps / elapsed,
+                "exchange": merge_path,
+                "orders_per_sec": orders_per_step * args.steps / elapsed,
                 "lines_kernel_geometry": f"{wg} workgroups x {wv} waves",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
+                "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_note,
                 "kernel": "k_lines", "kernel_ms": k_ms["lines"], "algorithmic_bytes_per_launch": b_lines,
                 "other_kernels_ms": {k: v for k, v in k_ms.items() if k != "lines"},
-                "whole_step_algorithmic_GBs": (12 * ds.n_lines + 12 * ds.n_orders + 16 * P + 8 * Cn)
-                / (elapsed / args.steps) / 1e9,
-                "achievable_same_traffic_GBs": ACHIEVABLE_SAME_TRAFFIC_GBS,
-                "frac_of_achievable": achieved / ACHIEVABLE_SAME_TRAFFIC_GBS,
+                # the whole step (every kernel of it) against the same peak: 12 B per line, 12 B per order,
+                # 16 B per product, 8 B per customer, over the wall time of a step on this GPU
+                "whole_step_algorithmic_bytes": b_step,
+                "whole_step_algorithmic_GBs": b_step / (elapsed / args.steps) / 1e9,
+                "whole_step_frac": b_step / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS,
+                "whole_step_device_ms": step_ms_device,
+                # measured in this run: a plain device-to-device copy (read + written bytes per second)
+                "device_copy_GBs": copy_gbs,
+                "frac_of_device_copy": achieved / copy_gbs if copy_gbs else None,
                 "launches_per_step": 3 if ds.n_orders >= 4_000_000 else 4,
             },
         }
@@ -243,6 +365,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ds, args.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)
 
+    if com:
+        com.cerrar()
     motor.cerrar()
     if world > 1:
         dist.destroy_process_group()

@@ -287,6 +287,59 @@ int acmpc_host_alloc(acmpc_ctx* ctx, int64_t n_bytes, void** out);
 int acmpc_host_free(acmpc_ctx* ctx, void* p);
 
 /* ------------------------------------------------------------------------
+ * More than one GPU.  Orders are independent (each venta row owns its detalle rows,
+ * process/confirmcompra.php:24,35-37), so shard g of G owns the contiguous order-index range
+ * [floor(g*M/G), floor((g+1)*M/G)) and exactly the lines of those orders; per-order totals stay
+ * with their shard.  Only the per-product and per-customer vectors cross shards: ONE in-place
+ * all-reduce (sum, int64) of the concatenated [product_qty | customer_total_cents] vector through
+ * RCCL over xGMI.  Integer sums do not depend on the order of reduction, so the merged result is
+ * bit-identical for any number of shards.  RCCL (librccl.so.1) is loaded when the first of these
+ * functions is called; without it they return ACMPC_E_STATE.
+ * Stands where the reference opens one connection per statement (ejecutarSQL::conectar,
+ * library/consulSQL.php:5-16): one context and one communicator rank per GPU, either all in one
+ * process (acmpc_comm_init_all, the route of a PHP worker) or one process per GPU
+ * (acmpc_comm_id + acmpc_comm_init_rank, the id carried to the other processes by any channel).
+ * ---------------------------------------------------------------------- */
+typedef struct acmpc_comm acmpc_comm;
+#define ACMPC_COMM_ID_BYTES 128
+
+/* One process per GPU: rank 0 obtains an id, every rank (its context's device current or not)
+ * joins with the same id.  Collective: returns when all `world` ranks have called it. */
+int acmpc_comm_id(char* id128);
+int acmpc_comm_init_rank(acmpc_comm** out, acmpc_ctx* ctx, const char* id128, int rank, int world);
+
+/* One process, n_devices GPUs: out[g] becomes the rank of ctxs[g] (contexts on distinct devices). */
+int acmpc_comm_init_all(acmpc_comm** out, acmpc_ctx* const* ctxs, int n_devices);
+void acmpc_comm_destroy(acmpc_comm* comm);
+
+/* The exchange step for one rank: d_values[count] (device, int64) becomes the element-wise sum over all
+ * ranks, in place, enqueued on hip_stream.  With one process per GPU every process calls it once per
+ * step; a single process that drives several ranks must use acmpc_merge_group_device instead (the
+ * ranks' calls have to be issued together). */
+int acmpc_merge_device(acmpc_ctx* ctx, acmpc_comm* comm, int64_t* d_values, int64_t count, void* hip_stream);
+int acmpc_merge_group_device(acmpc_ctx* const* ctxs, acmpc_comm* const* comms, int n_devices,
+                             int64_t* const* d_values, int64_t count, void* const* hip_streams);
+
+/*
+ * acmpc_aggregate over n_devices GPUs from one process: cuts the HOST columns on order boundaries as
+ * described above, copies every shard to its device, runs the device path there, merges the product
+ * and customer vectors with the one all-reduce, and copies the results back (order totals from their
+ * shards).  Every context must hold the same product table (acmpc_set_products on each).  Same
+ * arguments, results and error behaviour as acmpc_aggregate; with n_devices == 1 the results equal
+ * acmpc_aggregate's bit for bit (as they do for any n_devices).
+ * Replaces the loops of process/carrito.php:12-18 and process/confirmcompra.php:24,35-37 like
+ * acmpc_aggregate, for all carts at once and all GPUs of the node.
+ */
+int acmpc_aggregate_sharded(acmpc_ctx* const* ctxs, acmpc_comm* const* comms, int n_devices,
+                            const int32_t* order_id, const int32_t* product_idx, const int32_t* qty,
+                            int64_t n_lines,
+                            const int32_t* order_customer, int64_t n_orders,
+                            int32_t order_id_base, int32_t n_customers,
+                            int64_t* out_order_total_cents,
+                            int64_t* out_product_qty,
+                            int64_t* out_customer_total_cents);
+
+/* ------------------------------------------------------------------------
  * Text ingest: `detalle` rows as SQL-dump / CSV text -> the three int32 columns.
  *
  * Accepted text (the shapes the reference itself writes):

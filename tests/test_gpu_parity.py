@@ -360,8 +360,7 @@ def test_shards_merge_to_the_single_device_result(motor, oracle):
 
 @pytest.mark.parametrize("zipf", [0, 1])
 def test_full_size_100m_lines(motor, oracle, zipf):
-    """The benchmark's primary configuration, 100 M lines on one GPU (also the per-GPU share of the sharded
-    1 G-line configurations): size-independent invariants, then the
+    """The benchmark's primary configuration, 100 M lines on one GPU: size-independent invariants, then the
     C oracle itself on the same columns (it needs ~0.2 s for 100M lines)."""
     import torch
     n, p, c = 100_000_000, 10_000, 100_000
@@ -377,6 +376,34 @@ def test_full_size_100m_lines(motor, oracle, zipf):
     np.testing.assert_array_equal(tot.cpu().numpy(), etot)
     np.testing.assert_array_equal(pq.cpu().numpy(), epq)
     np.testing.assert_array_equal(ct.cpu().numpy(), ect)
+
+
+@pytest.mark.parametrize("rank", [0, 7])
+@pytest.mark.parametrize("zipf", [0, 1])
+def test_one_shard_of_the_1g_line_configurations(motor, oracle, zipf, rank):
+    """The per-GPU workload of the two 8-GPU configurations (1 G lines over 8 GPUs, uniform and Zipf
+    products), run on one GPU at its true shape: shard `rank` of 8 holds about 125 M lines whose global line
+    indices and order ids lie far from zero (rank 7: lines from 875 M, order ids from about 219 M).  The device
+    generator must produce exactly the oracle's slice, and the engine exactly the oracle's sums on it."""
+    n_total, p, c, world = 1_000_000_000, 10_000, 100_000, 8
+    ds = sintetico.generar(motor, n_total, p, c, zipf=bool(zipf), qty_mode=0, rank=rank, world=world)
+    m_total = ds.n_orders_total
+    lo, hi = (m_total * rank) // world, (m_total * (rank + 1)) // world
+    d = oracle.synth(n_total, p, c, zipf=zipf, qty_mode=0, order_lo=lo, order_hi=hi)
+    assert d["n_orders_total"] == m_total and d["order_id_base"] == ds.order_id_base == 5 + lo
+    assert 124_000_000 < ds.n_lines < 126_000_000 and ds.n_orders == hi - lo
+    for name, t in (("order_id", ds.order_id), ("product_idx", ds.product_idx), ("qty", ds.qty),
+                    ("order_customer", ds.order_customer)):
+        assert np.array_equal(t.cpu().numpy(), d[name]), name
+    tot, pq, ct = _device_run(motor, ds)
+    etot, epq, ect, flags = oracle.aggregate(d["order_id"], d["product_idx"], d["qty"], d["order_customer"],
+                                             d["order_id_base"], c, ds.price_cents, threads=8)
+    assert flags == 0
+    np.testing.assert_array_equal(tot.cpu().numpy(), etot)
+    np.testing.assert_array_equal(pq.cpu().numpy(), epq)
+    np.testing.assert_array_equal(ct.cpu().numpy(), ect)
+    if zipf:
+        assert int(epq[0]) > 10 * int(epq[p // 2])           # the hot product really is hot in this shard
 
 
 # ---- rows not grouped by order (concurrent checkouts interleave their detalle inserts) ------------
