@@ -4,6 +4,7 @@
 #include "acmpc_ingest.hpp"
 #include "acmpc_emit.hpp"
 #include "acmpc_comm.hpp"
+#include "acmpc_partition.hpp"
 #include "../../include/acmpc.h"
 
 #include <algorithm>
@@ -85,6 +86,11 @@ struct acmpc_ctx {
   DevBuf<int64_t> d_edge_total;
   int fuse = 1;                     // 0: always the four-launch sequence (ACMPC_FUSE=0)
   DevBuf<uint32_t> d_cust_slab;
+  // order-restoring path for rows in any order: two sets of (order index, value) records, counters
+  DevBuf<uint32_t> d_part_idx[2];
+  DevBuf<int64_t> d_part_val[2];
+  DevBuf<unsigned long long> d_part_meta;
+  int partition = 1;                // 0: rows in any order always go through the atomic kernel (ACMPC_PARTITION=0)
   DevBuf<unsigned long long> d_cust_carry;
   uint32_t* d_status = nullptr;
   bool carry_dirty = false;     // a launch failed half way: clear the carries before the next call
@@ -414,6 +420,52 @@ int launch_lines_any(acmpc_ctx* ctx, const LinesPlan& pl, size_t lds_bytes, cons
   return ACMPC_OK;
 }
 
+// The order-restoring path (acmpc_partition.hpp): queues count, scan, two scatter passes and the per-bucket
+// reduce.  On return order_total holds every order's total; with !totals_only the stock-delta slabs of
+// `blocks` workgroups are in prod_slab as after k_lines.
+constexpr size_t kPartLdsA = (size_t)2 * kPartCntPitch * 4 + 34 * 8 + (size_t)kPartRound * (8 + 4 + 2);
+constexpr size_t kPartLdsB = (size_t)2 * (kPartMaxBuckets + 4) * 4 + (size_t)kPartMaxBuckets * 8 + (size_t)kPartRoundB * (8 + 4 + 2);
+
+bool partition_fits(const acmpc_ctx* ctx, const LinesPlan& lp, int64_t n_orders) {
+  return ctx->partition && !ctx->force_global_tables && lp.lds_tables && lp.price_lds && lp.hist_lds && lp.price32 &&
+         n_orders <= (int64_t)kPartMaxBuckets * kPartBucket &&
+         (size_t)ctx->p_pad * 8 + kPartLdsA + kLdsReserve <= (size_t)kMaxLds;
+}
+
+int launch_partition(acmpc_ctx* ctx, PartArgs& a, int blocks, hipStream_t st) {
+  int rc;
+  const size_t n = (size_t)std::max<int64_t>(a.n_lines, 1);
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = ensure(ctx, ctx->d_part_idx[k], n))) return rc;
+    if ((rc = ensure(ctx, ctx->d_part_val[k], n))) return rc;
+  }
+  const size_t n_meta = (size_t)kPartMaxBuckets * 3 + kPartCoarse + 24;
+  if ((rc = ensure(ctx, ctx->d_part_meta, n_meta))) return rc;
+  a.counts = ctx->d_part_meta.p;
+  a.bucket_off = a.counts + kPartMaxBuckets;
+  a.cursor_b = a.bucket_off + kPartMaxBuckets + 8;
+  a.cursor_a = a.cursor_b + kPartMaxBuckets;
+  a.changes = a.cursor_a + kPartCoarse;
+  a.mode = a.changes + 1;
+  a.idx_a = ctx->d_part_idx[0].p; a.val_a = reinterpret_cast<long long*>(ctx->d_part_val[0].p);
+  a.idx_b = ctx->d_part_idx[1].p; a.val_b = reinterpret_cast<long long*>(ctx->d_part_val[1].p);
+  a.n_buckets = (int32_t)((a.n_orders + kPartBucket - 1) / kPartBucket);
+  HIPCHK(ctx, hipMemsetAsync(a.counts, 0, (size_t)kPartMaxBuckets * 8, st));
+  HIPCHK(ctx, hipMemsetAsync(a.changes, 0, 8, st));
+  hipLaunchKernelGGL(k_part_count, dim3(blocks), dim3(kPartThreads), 0, st, a);
+  hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(kPartThreads), 0, st, a);
+  const size_t lds_a = (size_t)ctx->p_pad * 8 + kPartLdsA;
+  if ((rc = set_dyn_lds(ctx, k_part_scatter_a, lds_a))) return rc;
+  hipLaunchKernelGGL(k_part_scatter_a, dim3(blocks), dim3(kPartThreads), lds_a, st, a);
+  if ((rc = set_dyn_lds(ctx, k_part_scatter_b, kPartLdsB))) return rc;
+  hipLaunchKernelGGL(k_part_scatter_b, dim3(blocks), dim3(kPartThreads), kPartLdsB, st, a);
+  const size_t lds_c = (size_t)kPartBucket * 8;
+  if ((rc = set_dyn_lds(ctx, k_part_reduce, lds_c))) return rc;
+  hipLaunchKernelGGL(k_part_reduce, dim3(std::max(1, a.n_buckets)), dim3(kPartThreads), lds_c, st, a);
+  HIPCHK(ctx, hipGetLastError());
+  return ACMPC_OK;
+}
+
 int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32_t* d_product_idx,
                           const int32_t* d_qty, int64_t n_lines, const int32_t* d_order_customer,
                           int64_t n_orders, int32_t base, int32_t n_customers, int64_t* d_tot,
@@ -565,9 +617,34 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.descuento_mode = d_desc ? life->descuento_mode : 0;
     a.order_state = d_state;
     a.no_hist = sp.use ? 1 : 0;
+    a.run_if_zero = nullptr;
 
     if (!fixed_ws) ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
-    if (any_order) {
+    // rows in any order: the order-restoring path when the sizes allow it, else one global atomic per run
+    const bool part_ok = !life && !fixed_ws && partition_fits(ctx, lp, n_orders);
+    const int part_blocks = lp.blocks;
+    PartArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.order_id = d_order_id; pa.product_idx = d_product_idx; pa.qty = d_qty; pa.n_lines = n_lines;
+    pa.base = base; pa.n_orders = (int32_t)n_orders; pa.price = ctx->d_price.p; pa.n_products = P; pa.p_pad = ctx->p_pad;
+    {
+      const uint64_t rounds = ((uint64_t)n_lines + kPartRound - 1) / kPartRound;
+      const uint64_t per_block = ((rounds + part_blocks - 1) / part_blocks) * kPartRound;
+      pa.q_small = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(65536, 0xffffffffull / std::max<uint64_t>(1, per_block)));
+    }
+    pa.prod_carry = w.prod_carry; pa.order_total = d_tot; pa.status = w.status;
+    if (any_order && part_ok) {
+      // count + decide on the device; then either the moving passes or the atomic kernel does the work
+      pa.prod_slab = w.prod_slab;                       // (lp.blocks slabs, whichever path fills them)
+      if ((rc = launch_partition(ctx, pa, lp.blocks, st))) return rc;
+      hipLaunchKernelGGL(k_zero_if_unsorted, dim3(ctx->n_cu * 4), dim3(256), 0, st, d_tot, n_orders, w.status, 0, pa.mode);
+      HIPCHK(ctx, hipGetLastError());
+      a.run_if_zero = pa.mode;
+      const size_t tables = (size_t)ctx->p_pad * 8;     // (partition_fits: both tables in LDS, 32-bit prices)
+      if ((rc = launch_lines_any<int32_t, true>(ctx, lp, tables, a, st))) return rc;
+      a.run_if_zero = nullptr;
+    }
+    else if (any_order) {
       HIPCHK(ctx, hipMemsetAsync(d_tot, 0, (size_t)n_orders * 8, st));
       const size_t tables = !lp.lds_tables ? 0 : (size_t)ctx->p_pad * ((lp.price_lds ? (lp.price32 ? 4 : 8) : 0) + (lp.hist_lds ? 4 : 0));
       if (life_lines) {
@@ -638,7 +715,15 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       LinesArgs b = a;
       b.n_tiles = ap.n_tiles; b.tiles_per_wave = ap.tiles_per_wave; b.tile_lines = ap.tile_lines;
       b.price_in_lds = ap.price_lds ? 1 : 0; b.only_if_unsorted = 1; b.totals_only = 1;
-      hipLaunchKernelGGL(k_zero_if_unsorted, dim3(ctx->n_cu * 4), dim3(256), 0, st, d_tot, n_orders, w.status);
+      if (part_ok) {
+        // count how far from grouped the rows are and let the order-restoring path redo the totals if they are
+        // far (every kernel of it leaves at once if the rows were grouped after all)
+        pa.totals_only = 1; pa.only_if_unsorted = 1;
+        if ((rc = launch_partition(ctx, pa, lp.blocks, st))) return rc;
+        b.run_if_zero = pa.mode;
+      }
+      {
+      hipLaunchKernelGGL(k_zero_if_unsorted, dim3(ctx->n_cu * 4), dim3(256), 0, st, d_tot, n_orders, w.status, 1, b.run_if_zero);
       HIPCHK(ctx, hipGetLastError());
       const size_t tables = !ap.lds_tables ? 0 : (size_t)ctx->p_pad * ((ap.price_lds ? (ap.price32 ? 4 : 8) : 0) + (ap.hist_lds ? 4 : 0));
       if (life_lines) {
@@ -650,6 +735,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       else if (ap.price32) rc = launch_lines_any<int32_t, true>(ctx, ap, tables, b, st);
       else rc = launch_lines_any<int64_t, true>(ctx, ap, tables, b, st);
       if (rc) return rc;
+      }
       hipLaunchKernelGGL(k_clear_unsorted, dim3(1), dim3(64), 0, st, w.status);
       HIPCHK(ctx, hipGetLastError());
     }
@@ -796,6 +882,7 @@ ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
   ctx->k1_lpl = env_int("ACMPC_K1_LPL", 4);
   ctx->k2_threads = env_int("ACMPC_K2_THREADS", 1024);
   ctx->fuse = env_int("ACMPC_FUSE", 1);
+  ctx->partition = env_int("ACMPC_PARTITION", 1);
   if (env_int("ACMPC_DEV_ABLATE", 0) == 1) {
     ctx->ablate_fix = env_int("ACMPC_FIX_ABLATE", 0);
     ctx->ablate_k2 = env_int("ACMPC_K2_ABLATE", 0);
@@ -841,6 +928,8 @@ ACMPC_API void acmpc_destroy(acmpc_ctx* ctx) {
   release(ctx->s_order_total); release(ctx->s_product_qty); release(ctx->s_customer_total); release(ctx->s_merged);
   release(ctx->s_synth_off); release(ctx->s_synth_cdf);
   release(ctx->d_edge_idx); release(ctx->d_edge_total);
+  release(ctx->d_part_idx[0]); release(ctx->d_part_idx[1]); release(ctx->d_part_val[0]); release(ctx->d_part_val[1]);
+  release(ctx->d_part_meta);
   release(ctx->d_dict); release(ctx->d_dict_disp); release(ctx->d_codes); release(ctx->d_chunk_rows); release(ctx->d_ing_tables);
   release(ctx->s_text); release(ctx->d_chunk_bytes); release(ctx->s_emit_value);
   release(ctx->s_line_price); release(ctx->s_order_state); release(ctx->s_order_descuento);

@@ -1,0 +1,413 @@
+// acmpc_partition.hpp — gfx950 device code of the order-restoring path for `detalle` rows in any order
+// (concurrent checkouts interleave their inserts, process/confirmcompra.php:27,35-37; the table has no key
+// that would order them, store.sql:192-194).
+//
+// One 64-bit global atomic per line is bound by the part's scattered-atomic rate (about 23 G/s).  Instead
+// the lines are moved next to the other lines of their order's neighbourhood, and summed there in LDS:
+//
+//   k_part_count      lines per bucket of 16384 consecutive orders (one pass over order_id), and how often
+//                     the order id changes from one line to the next
+//   k_part_scan       bucket offsets, cursors of the two scatter passes; decides whether the rows are far
+//                     enough from grouped for this path (else k_lines_any, one atomic per run, is cheaper)
+//   k_part_scatter_a  (order index, price * qty) of every line, written into one of 32 coarse bins
+//                     (64 buckets each); the stock deltas are taken here as well
+//   k_part_scatter_b  every coarse bin split into its buckets
+//   k_part_reduce     one workgroup per bucket: 64-bit adds into a 128 KB LDS table, totals written once
+//
+// Both scatter passes bin a round of records (4096 / 8192) in LDS and write whole runs, and reserve the place
+// of a run with one returning atomic per (round, bin): the records of a bucket end up in no particular order,
+// which integer sums do not mind.  HBM-bound byte work; no MFMA.
+#pragma once
+#include "acmpc_kernels.hpp"
+
+namespace acmpc {
+
+constexpr int kPartShift = 14;                         // 16384 orders per bucket: int64 cells fill 128 KB of LDS
+constexpr int kPartBucket = 1 << kPartShift;
+constexpr int kPartMaxBuckets = 2048;                  // hence at most 2^25 orders on this path
+constexpr int kPartCoarseShift = 6;                    // 64 buckets per coarse bin, at most 32 coarse bins
+constexpr int kPartCoarse = kPartMaxBuckets >> kPartCoarseShift;
+constexpr int kPartThreads = 1024;
+constexpr int kPartWaves = kPartThreads / kWave;
+constexpr int kPartRound = kPartThreads * 4;           // records a workgroup bins per round
+constexpr int kPartCntPitch = 36;                      // counters per wave in pass A: 32 bins, the drop bin, padding
+
+struct PartArgs {
+  const int32_t* order_id;
+  const int32_t* product_idx;
+  const int32_t* qty;
+  int64_t n_lines;
+  int32_t base;
+  int32_t n_orders;
+  int32_t n_buckets;                  // ceil(n_orders / 16384)
+  const int64_t* price;               // [P + 1], entry P is the null product
+  int32_t n_products, p_pad;
+  uint32_t q_small;                   // quantities in [0, q_small) go to the 32-bit LDS histogram
+  uint32_t* prod_slab;                // [gridDim.x][p_pad] (pass A)
+  unsigned long long* prod_carry;     // [P] 64-bit cells for every other quantity
+  int32_t totals_only;                // 1: the stock deltas are already known (fallback of the grouped pass)
+  int32_t only_if_unsorted;           // 1: leave at once unless the grouped pass raised kStUnsorted
+  unsigned long long* counts;         // [kPartMaxBuckets] lines per bucket (zero on entry of k_part_count)
+  unsigned long long* bucket_off;     // [kPartMaxBuckets + 1] first record of every bucket
+  unsigned long long* cursor_a;       // [kPartCoarse] next free record of every coarse bin
+  unsigned long long* cursor_b;       // [kPartMaxBuckets] next free record of every bucket
+  uint32_t* idx_a; long long* val_a;  // records after pass A   [n_lines]
+  uint32_t* idx_b; long long* val_b;  // records after pass B   [n_lines]
+  int64_t* order_total;               // [n_orders]
+  uint32_t* status;
+  // How far from grouped the rows are decides which path sums them: k_part_count counts the places where the
+  // order id changes from one line to the next (inside every lane's four lines: three of four places), and
+  // k_part_scan sets *mode to 1 (this path) when the estimate exceeds 0.4 changes per line, else to 0 (one
+  // 64-bit atomic per run of equal ids, k_lines_any, which costs about 0.05 ms per million runs).
+  unsigned long long* changes;        // zero on entry of k_part_count
+  unsigned long long* mode;
+};
+
+__device__ __forceinline__ bool part_skip(const PartArgs& a) {
+  return a.only_if_unsorted && !(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStUnsorted);
+}
+// the scatter passes and the reduce: also when the rows are near enough to grouped for the atomic kernel
+__device__ __forceinline__ bool part_skip_moving(const PartArgs& a) { return part_skip(a) || *a.mode == 0ull; }
+
+// Lanes of the wave whose key equals this lane's (every lane takes part): BITS ballots.
+template <int BITS>
+__device__ __forceinline__ unsigned long long part_peers(uint32_t key) {
+  unsigned long long m = ~0ull;
+#pragma unroll
+  for (int b = 0; b < BITS; ++b) {
+    const bool bit = (key >> b) & 1u;
+    const unsigned long long s = __ballot(bit);
+    m &= bit ? s : ~s;
+  }
+  return m;
+}
+
+// Position of this lane's record among the records of its bin in this round: the lanes of a wave that share
+// a bin take one returning add on the bin's counter between them (made by the lowest of them), so adds to
+// one LDS word from inside a wave never collide, however the keys are distributed.
+template <int BITS>
+__device__ __forceinline__ uint32_t part_rank(uint32_t* s_cnt, uint32_t key, int lane) {
+  const unsigned long long m = part_peers<BITS>(key);
+  const unsigned long long below = lane == 0 ? 0ull : (m & (~0ull >> (64 - lane)));
+  const int leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = __hip_atomic_fetch_add(&s_cnt[key], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  base = (uint32_t)__shfl((int)base, leader);
+  return base + (uint32_t)__popcll(below);
+}
+
+// ---- lines per bucket ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(kPartThreads) k_part_count(PartArgs a) {
+  __shared__ uint32_t s_cnt[kPartMaxBuckets];
+  if (part_skip(a)) return;                               // uniform: the whole grid leaves
+  for (int i = (int)threadIdx.x; i < kPartMaxBuckets; i += kPartThreads) s_cnt[i] = 0u;
+  __syncthreads();
+  uint32_t st = 0;
+  uint32_t changes = 0;
+  const long long n4 = a.n_lines / 4;
+  for (long long q = (long long)blockIdx.x * kPartThreads + threadIdx.x; q < n4; q += (long long)gridDim.x * kPartThreads) {
+    const int4 v = load_stream16(a.order_id + 4 * q);
+    const int ids[4] = {v.x, v.y, v.z, v.w};
+    changes += (v.x != v.y) + (v.y != v.z) + (v.z != v.w);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t idx = (uint32_t)ids[i] - (uint32_t)a.base;
+      const bool ok = idx < (uint32_t)a.n_orders;
+      if (!ok) st |= kStOrderRange;
+      // rows that are grouped after all put every lane of a wave into one bucket: those lanes share one add
+      const uint32_t bucket = ok ? idx >> kPartShift : 0xffffffffu;
+      const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)bucket);
+      const unsigned long long same = __ballot(bucket == b0);
+      const bool shared = __popcll(same) >= 8 && bucket == b0;
+      if (shared) {
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)same) - 1 && ok)
+          __hip_atomic_fetch_add(&s_cnt[bucket], (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (ok) {
+        __hip_atomic_fetch_add(&s_cnt[bucket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  if (blockIdx.x == 0 && (long long)threadIdx.x < a.n_lines - 4 * n4) {
+    const uint32_t idx = (uint32_t)a.order_id[4 * n4 + threadIdx.x] - (uint32_t)a.base;
+    if (idx < (uint32_t)a.n_orders) __hip_atomic_fetch_add(&s_cnt[idx >> kPartShift], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else st |= kStOrderRange;
+  }
+  if (st) atomicOr(a.status, st);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) changes += __shfl_xor(changes, d);
+  if ((threadIdx.x & 63) == 0 && changes) atomicAdd(a.changes, (unsigned long long)changes);
+  __syncthreads();
+  for (int i = (int)threadIdx.x; i < a.n_buckets; i += kPartThreads)
+    if (s_cnt[i]) atomicAdd(&a.counts[i], (unsigned long long)s_cnt[i]);
+}
+
+// ---- offsets and cursors (one workgroup; two buckets per thread) -----------------------------------
+__global__ void __launch_bounds__(kPartThreads) k_part_scan(PartArgs a) {
+  __shared__ unsigned long long s_w[kPartWaves];
+  if (part_skip(a)) return;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long c0 = 2 * tid < a.n_buckets ? a.counts[2 * tid] : 0ull;
+  const unsigned long long c1 = 2 * tid + 1 < a.n_buckets ? a.counts[2 * tid + 1] : 0ull;
+  const long long incl = wave_inclusive_scan((long long)(c0 + c1));
+  if (lane == 63) s_w[wave] = (unsigned long long)incl;
+  __syncthreads();
+  unsigned long long off = (unsigned long long)incl - (c0 + c1);
+  for (int w = 0; w < wave; ++w) off += s_w[w];
+  a.bucket_off[2 * tid] = off;
+  a.bucket_off[2 * tid + 1] = off + c0;
+  a.cursor_b[2 * tid] = off;
+  a.cursor_b[2 * tid + 1] = off + c0;
+  if (((2 * tid) & ((1 << kPartCoarseShift) - 1)) == 0) a.cursor_a[(2 * tid) >> kPartCoarseShift] = off;
+  if (tid == kPartThreads - 1) a.bucket_off[kPartMaxBuckets] = off + c0 + c1;
+  a.counts[2 * tid] = 0ull;                                 // clean for the next call
+  a.counts[2 * tid + 1] = 0ull;
+  if (tid == 0) {
+    // three of every four places were looked at: changes per line is about (4/3) * counted / n_lines
+    const unsigned long long c = *a.changes;
+    *a.mode = (c * 10ull > (unsigned long long)a.n_lines * 3ull) ? 1ull : 0ull;
+    *a.changes = 0ull;
+  }
+}
+
+// The binning both scatter passes share.  On entry every thread holds up to four records (bin, idx, val;
+// bin == n_bins: not a record) and has taken its rank inside (wave, bin) from the wave's counters; s_tot
+// holds the records per bin of this round.  Reserves the runs, stages the records bin by bin in LDS and
+// writes the runs out.
+//   s_start [n_bins + 1]   first staging slot of every bin      s_gbase [n_bins]   first record of its run
+template <int N_BINS, int K>
+__device__ __forceinline__ void part_write_round(const uint32_t (&bin)[K], const uint32_t (&idx)[K], const long long (&val)[K],
+                                                 const uint32_t (&pos)[K], uint32_t* s_start, unsigned long long* s_gbase,
+                                                 uint32_t* s_idx, long long* s_val, unsigned short* s_bin,
+                                                 uint32_t* idx_out, long long* val_out) {
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    if (bin[i] < (uint32_t)N_BINS) {
+      const uint32_t p = s_start[bin[i]] + pos[i];
+      s_idx[p] = idx[i];
+      s_val[p] = val[i];
+      s_bin[p] = (unsigned short)bin[i];
+    }
+  }
+  __syncthreads();
+  const uint32_t total = s_start[N_BINS];
+  for (uint32_t e = threadIdx.x; e < total; e += kPartThreads) {
+    const uint32_t b = s_bin[e];
+    const unsigned long long g = s_gbase[b] + (e - s_start[b]);
+    idx_out[g] = s_idx[e];
+    val_out[g] = s_val[e];
+  }
+}
+
+// ---- pass A: lines -> (order index, value) records in 32 coarse bins; stock deltas --------------------
+// LDS: [price int32 p_pad][histogram p_pad][counters 36][start 36][gbase 34 x 8][val 4096 x 8][idx 4096 x 4][bin 4096 x 2]
+__global__ void __launch_bounds__(kPartThreads) k_part_scatter_a(PartArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  if (part_skip_moving(a)) return;
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  int32_t* s_price = reinterpret_cast<int32_t*>(smem);
+  uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem) + a.p_pad;
+  uint32_t* s_cnt = s_hist + a.p_pad;                                     // [33] (+3): records per bin of this round
+  uint32_t* s_start = s_cnt + kPartCntPitch;                              // [33] (+3)
+  unsigned long long* s_gbase = reinterpret_cast<unsigned long long*>(s_start + kPartCntPitch);   // [32] (+2)
+  long long* s_val = reinterpret_cast<long long*>(s_gbase + 34);          // [4096]
+  uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_val + kPartRound);      // [4096]
+  unsigned short* s_bin = reinterpret_cast<unsigned short*>(s_idx + kPartRound);      // [4096]
+  const bool hist = !a.totals_only;
+  for (int i = tid; i < a.n_products + 1; i += kPartThreads) { s_price[i] = (int32_t)a.price[i]; s_hist[i] = 0u; }
+  if (tid < kPartCntPitch) s_cnt[tid] = 0u;
+  __syncthreads();
+  const uint32_t P = (uint32_t)a.n_products;
+  const long long n_rounds = (a.n_lines + kPartRound - 1) / kPartRound;
+  uint32_t st = 0;
+
+  auto load_round = [&](long long r, int (&ids)[4], int (&prs)[4], int (&qs)[4]) {
+    const long long l0 = r * kPartRound + (long long)tid * 4;
+    if (l0 + 4 <= a.n_lines) {
+      load_lines<4>(a.order_id + l0, ids);
+      load_lines<4>(a.product_idx + l0, prs);
+      load_lines<4>(a.qty + l0, qs);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool in = l0 + i < a.n_lines;
+        ids[i] = in ? a.order_id[l0 + i] : a.base - 1;      // outside the order range: dropped below, not reported
+        prs[i] = in ? a.product_idx[l0 + i] : -1;
+        qs[i] = in ? a.qty[l0 + i] : 0;
+      }
+    }
+  };
+
+  long long r = blockIdx.x;
+  int nid[4], npr[4], nq[4];
+  if (r < n_rounds) load_round(r, nid, npr, nq);
+  for (; r < n_rounds; r += gridDim.x) {
+    int ids[4], prs[4], qs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ids[i] = nid[i]; prs[i] = npr[i]; qs[i] = nq[i]; }
+    const long long l0 = r * kPartRound + (long long)tid * 4;
+    if (r + gridDim.x < n_rounds) load_round(r + gridDim.x, nid, npr, nq);     // in flight while this round is binned
+    uint32_t bin[4], idx[4], pos[4];
+    long long val[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      idx[i] = (uint32_t)ids[i] - (uint32_t)a.base;
+      const bool ok = idx[i] < (uint32_t)a.n_orders;
+      if (!ok && l0 + i < a.n_lines) st |= kStOrderRange;
+      bin[i] = ok ? (idx[i] >> (kPartShift + kPartCoarseShift)) : (uint32_t)kPartCoarse;
+      const uint32_t pi = min((uint32_t)prs[i], P);
+      val[i] = (long long)s_price[pi] * (long long)qs[i];
+      if (hist) {
+        if ((uint32_t)qs[i] < a.q_small)
+          __hip_atomic_fetch_add(&s_hist[pi], (uint32_t)qs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else if (pi < P)
+          atomicAdd(&a.prod_carry[pi], (unsigned long long)(long long)qs[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pos[i] = part_rank<6>(s_cnt, bin[i], lane);
+    __syncthreads();
+    // one thread per bin: where the bin starts in the staging area; reserve its run
+    if (tid <= kPartCoarse) {
+      const uint32_t mine = tid < kPartCoarse ? s_cnt[tid] : 0u;          // the drop bin takes no room
+      uint32_t incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+      s_start[tid] = incl - mine;                                          // s_start[32] == records of this round
+      if (mine) s_gbase[tid] = atomicAdd(&a.cursor_a[tid], (unsigned long long)mine);
+    }
+    __syncthreads();
+    part_write_round<kPartCoarse, 4>(bin, idx, val, pos, s_start, s_gbase, s_idx, s_val, s_bin, a.idx_a, a.val_a);
+    if (tid < kPartCntPitch) s_cnt[tid] = 0u;          // (nobody reads the counters after the barrier above)
+    __syncthreads();
+  }
+  if (st) atomicOr(a.status, st);
+  if (hist) {
+    uint32_t* slab = a.prod_slab + (size_t)blockIdx.x * a.p_pad;
+    for (int i = tid; i < a.n_products; i += kPartThreads) slab[i] = s_hist[i];
+  }
+}
+
+// ---- pass B: records of the coarse bins -> records of the buckets ----------------------------------
+// Rounds of 8192 records (two groups of four per thread): the wait for the returning atomics that reserve
+// the runs comes once per round, and a round's records fall into the 64 to 128 buckets of one or two coarse
+// bins, so the longer the round the longer the runs.
+// LDS: [counters 2052][start 2052][gbase 2048 x 8][val 8192 x 8][idx 8192 x 4][bin 8192 x 2]
+constexpr int kPartRoundB = 2 * kPartRound;
+__global__ void __launch_bounds__(kPartThreads) k_part_scatter_b(PartArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  if (part_skip_moving(a)) return;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);                    // [2049] (+3): records per bucket of this round
+  uint32_t* s_start = s_cnt + kPartMaxBuckets + 4;                        // [2049] (+3)
+  unsigned long long* s_gbase = reinterpret_cast<unsigned long long*>(s_start + kPartMaxBuckets + 4);   // [2048]
+  long long* s_val = reinterpret_cast<long long*>(s_gbase + kPartMaxBuckets);
+  uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_val + kPartRoundB);
+  unsigned short* s_bin = reinterpret_cast<unsigned short*>(s_idx + kPartRoundB);
+  __shared__ uint32_t s_w[kPartWaves];
+  for (int i = tid; i < kPartMaxBuckets + 4; i += kPartThreads) s_cnt[i] = 0u;
+  __syncthreads();
+  const long long n_rec = (long long)a.bucket_off[kPartMaxBuckets];
+  const long long n_rounds = (n_rec + kPartRoundB - 1) / kPartRoundB;
+
+  // thread t holds records 4t .. 4t+3 of each half of the round
+  auto load_round = [&](long long r, uint32_t (&idx)[8], long long (&val)[8]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long long e0 = r * kPartRoundB + (long long)h * kPartRound + (long long)tid * 4;
+      if (e0 + 4 <= n_rec) {
+        const int4 v = load_stream16(reinterpret_cast<const int32_t*>(a.idx_a + e0));
+        idx[4 * h] = (uint32_t)v.x; idx[4 * h + 1] = (uint32_t)v.y; idx[4 * h + 2] = (uint32_t)v.z; idx[4 * h + 3] = (uint32_t)v.w;
+        long long q[4];
+        load_prices<4>(a.val_a + e0, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) val[4 * h + i] = q[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool in = e0 + i < n_rec;
+          idx[4 * h + i] = in ? a.idx_a[e0 + i] : 0xffffffffu;        // past the end: no bucket
+          val[4 * h + i] = in ? a.val_a[e0 + i] : 0ll;
+        }
+      }
+    }
+  };
+
+  long long r = blockIdx.x;
+  uint32_t nidx[8];
+  long long nval[8];
+  if (r < n_rounds) load_round(r, nidx, nval);
+  for (; r < n_rounds; r += gridDim.x) {
+    uint32_t bin[8], idx[8], pos[8];
+    long long val[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { idx[i] = nidx[i]; val[i] = nval[i]; }
+    if (r + gridDim.x < n_rounds) load_round(r + gridDim.x, nidx, nval);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bin[i] = min(idx[i] >> kPartShift, (uint32_t)kPartMaxBuckets);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pos[i] = part_rank<12>(s_cnt, bin[i], lane);
+    __syncthreads();
+    // one thread per pair of buckets: where they start in the staging area; reserve their runs
+    const uint32_t t0 = s_cnt[2 * tid], t1 = s_cnt[2 * tid + 1];
+    unsigned long long g0 = 0, g1 = 0;
+    if (t0) g0 = atomicAdd(&a.cursor_b[2 * tid], (unsigned long long)t0);       // in flight during the scan
+    if (t1) g1 = atomicAdd(&a.cursor_b[2 * tid + 1], (unsigned long long)t1);
+    uint32_t incl = t0 + t1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t off = incl - (t0 + t1);
+    for (int w = 0; w < wave; ++w) off += s_w[w];
+    s_start[2 * tid] = off;
+    s_start[2 * tid + 1] = off + t0;
+    if (tid == kPartThreads - 1) s_start[kPartMaxBuckets] = off + t0 + t1;
+    if (t0) s_gbase[2 * tid] = g0;
+    if (t1) s_gbase[2 * tid + 1] = g1;
+    __syncthreads();
+    part_write_round<kPartMaxBuckets, 8>(bin, idx, val, pos, s_start, s_gbase, s_idx, s_val, s_bin, a.idx_b, a.val_b);
+    s_cnt[2 * tid] = 0u;                               // (nobody reads the counters after the barrier above)
+    s_cnt[2 * tid + 1] = 0u;
+    if (tid == 0) s_cnt[kPartMaxBuckets] = 0u;
+    __syncthreads();
+  }
+}
+
+// ---- one workgroup per bucket: the totals of its 16384 orders ----------------------------------------
+__global__ void __launch_bounds__(kPartThreads) k_part_reduce(PartArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  if (part_skip_moving(a)) return;
+  unsigned long long* s_tab = reinterpret_cast<unsigned long long*>(smem);   // [16384]
+  const int tid = (int)threadIdx.x;
+  const int b = (int)blockIdx.x;
+  for (int i = tid * 2; i < kPartBucket; i += kPartThreads * 2) *reinterpret_cast<uint4*>(s_tab + i) = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  const long long lo = (long long)a.bucket_off[b], hi = (long long)a.bucket_off[b + 1];
+  // four records a thread in flight (a bucket starts anywhere, so single 4- and 8-byte loads; consecutive
+  // lanes read consecutive records)
+  for (long long e = lo + tid; e < hi; e += 4 * kPartThreads) {
+    uint32_t idx[4];
+    long long v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long long ek = e + (long long)k * kPartThreads;
+      const bool in = ek < hi;
+      idx[k] = in ? a.idx_b[ek] : 0u;
+      v[k] = in ? a.val_b[ek] : 0ll;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (e + (long long)k * kPartThreads < hi)
+        __hip_atomic_fetch_add(&s_tab[idx[k] & (kPartBucket - 1)], (unsigned long long)v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  const long long o0 = (long long)b * kPartBucket;
+  long long n = (long long)a.n_orders - o0;
+  if (n > kPartBucket) n = kPartBucket;
+  // o0 is a multiple of 16384 and order_total is 16-byte aligned: two totals per store
+  for (long long i = (long long)tid * 2; i + 1 < n; i += kPartThreads * 2)
+    *reinterpret_cast<uint4*>(a.order_total + o0 + i) = *reinterpret_cast<const uint4*>(s_tab + i);
+  if ((n & 1) && tid == 0) a.order_total[o0 + n - 1] = (int64_t)s_tab[n - 1];
+}
+
+}  // namespace acmpc

@@ -73,6 +73,57 @@ __global__ void __launch_bounds__(1024) k_lines_like(const int* __restrict__ a, 
   if (acc == 0x7fffffff) *sink = acc;
 }
 
+// Round-robin tiles: tile t belongs to wave t mod (waves of the grid); 8 B per lane per tile written
+//   MODE 0: by the wave itself, right away, at out[t * 64 + ragged + lane] (ragged != 0: the 512 bytes of a
+//           tile start in the middle of a cache line, as the order totals of a real tile do)
+//   MODE 1: staged in LDS by the 16 waves of the workgroup (their tiles are consecutive), and after a
+//           barrier written by the whole workgroup as one 8 KB piece; two staging buffers take turns
+template <int MODE>
+__global__ void __launch_bounds__(1024) k_tiles_like(const int* __restrict__ a, const int* __restrict__ b,
+                                                     const int* __restrict__ c, long long n_tiles,
+                                                     long long* __restrict__ out, int ragged, int* sink) {
+  __shared__ long long s_buf[2][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const long long n_waves = (long long)gridDim.x * wpb;
+  const long long g = (long long)blockIdx.x * wpb + wave;
+  const long long rounds = (n_tiles + n_waves - 1) / n_waves;
+  int acc = 0;
+  long long t = g;
+  long long off = (t < n_tiles ? t : 0) * kTile + lane * 4;
+  int4 xa = ntload4(a + off), xb = ntload4(b + off), xc = ntload4(c + off);
+  for (long long r = 0; r < rounds; ++r, t += n_waves) {
+    long long tn = t + n_waves; if (tn >= n_tiles) tn = n_tiles - 1;
+    const long long offn = tn * kTile + lane * 4;
+    const int4 ya = ntload4(a + offn), yb = ntload4(b + offn), yc = ntload4(c + offn);
+    const int f = fold(xa, xb, xc);
+    acc += f;
+    if (MODE == 0) {
+      if (t < n_tiles) out[t * 64 + ragged + lane] = f;
+    } else {
+      s_buf[r & 1][wave * 64 + lane] = f;
+      __syncthreads();
+      const long long t0 = t - wave;                       // the workgroup's first tile of this round
+      const long long e = t0 * 64 + ragged + threadIdx.x;
+      if (t0 + wave < n_tiles) out[e] = s_buf[r & 1][threadIdx.x];
+    }
+    xa = ya; xb = yb; xc = yc;
+  }
+  if (acc == 0x7fffffff) *sink = acc;
+}
+
+template <int MODE>
+void run_tiles(const char* name, int ragged, const int* a, const int* b, const int* c, long long n, long long* out, int* sink) {
+  auto kern = k_tiles_like<MODE>;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(1024), 0, 0, a, b, c, n / kTile, out, ragged, sink);
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(1024), 0, 0, a, b, c, n / kTile, out, ragged, sink);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+  printf("%-52s ragged %d: %.3f ms  %.2f TB/s\n", name, ragged, ms, 14.0 * n / ms / 1e9);
+  fflush(stdout);
+}
+
 // Customer-pass shape: R sibling workgroups (same blockIdx % 8) read the same stream of orders (4 B + 8 B per
 // order), waves of a workgroup take tiles round-robin, DEPTH tiles in flight.
 template <int DEPTH>
@@ -172,6 +223,12 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&a, n * 4 + 4096)); CK(hipMalloc(&b, n * 4 + 4096)); CK(hipMalloc(&c, n * 4 + 4096));
   CK(hipMalloc(&out, n / 4 * 8 + 4096)); CK(hipMalloc(&tot2, n / 4 * 8 + 4096)); CK(hipMalloc(&sink, 4));
   CK(hipMemset(a, 1, n * 4)); CK(hipMemset(b, 2, n * 4)); CK(hipMemset(c, 3, n * 4)); CK(hipMemset(tot2, 3, n / 4 * 8));
+  if (argc > 2) {
+    for (int rg : {0, 3}) { run_tiles<0>("round-robin tiles, each wave stores its tile", rg, a, b, c, n, out, sink);
+                            run_tiles<1>("round-robin tiles, workgroup stores 8 KB per round", rg, a, b, c, n, out, sink); }
+    run_lines<4>("run per wave, workgroup burst every 2 tiles", 256, 2, 0, a, b, c, n, out, sink);
+    return 0;
+  }
   run_lines<0>("store every tile", 256, 1, 0, a, b, c, n, out, sink);
   for (int cap : {2, 4, 8}) run_lines<1>("flush when full, per wave", 256, cap, 0, a, b, c, n, out, sink);
   for (int cap : {2, 4, 8}) run_lines<4>("flush every cap tiles, workgroup barrier", 256, cap, 0, a, b, c, n, out, sink);
