@@ -71,15 +71,37 @@ __device__ __forceinline__ bool ing_lower_is(const unsigned char* s, const char 
   for (int i = 0; i < 6; ++i) same &= (s[i] | 0x20u) == (uint32_t)word[i];
   return same;
 }
-__device__ __forceinline__ int ing_statement_row(const unsigned char* s) {
+// Bit 7 of every byte of w that equals the byte replicated in c4.
+__device__ __forceinline__ uint32_t ing_bytes_eq(uint32_t w, uint32_t c4) {
+  const uint32_t x = w ^ c4;
+  return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+}
+// `text` is the (4-byte aligned) LDS text, `pos` the offset of the line start in it.  The line is searched
+// a word at a time for '(' and newline; four words are requested together (the reads of one step do not
+// depend on each other).
+__device__ __forceinline__ int ing_statement_row(const unsigned char* text, int pos) {
+  const unsigned char* s = text + pos;
   if (!ing_lower_is(s, "insert")) return -1;
-  for (int j = 6; j <= kIngStmtReach; ++j) {
-    const uint32_t c = s[j];
-    if (c == '\n') return -1;
-    if (c != '(') continue;
-    int k = j - 1;
-    while (k > 0 && s[k] == ' ') --k;
-    if (k - 5 >= 6 && ing_lower_is(s + k - 5, "values")) return j;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(text);
+  const int first = pos + 6, last = pos + kIngStmtReach;            // bytes looked at: [first, last]
+  uint32_t ignore = (first & 3) ? ((1u << (8 * (first & 3))) - 1u) : 0u;   // bytes of the first word in front of `first`
+  for (int wi = first >> 2; (wi << 2) <= last; wi += 4) {
+    uint32_t x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = w[wi + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t hit = (ing_bytes_eq(x[k], 0x28282828u) | ing_bytes_eq(x[k], 0x0A0A0A0Au)) & ~ignore;
+      ignore = 0u;
+      while (hit) {
+        const int j = ((wi + k) << 2) + ((__ffs((int)hit) - 1) >> 3);     // offset in the text
+        hit &= hit - 1u;
+        if (j > last || text[j] == '\n') return -1;
+        int q = j - 1;
+        while (q > pos && text[q] == ' ') --q;
+        if (q - 5 >= first && ing_lower_is(text + q - 5, "values")) return j - pos;
+      }
+    }
   }
   return -1;
 }
@@ -509,10 +531,10 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
   for (;;) {
     // A ticket is kIngPerTicket consecutive chunks.  Tickets go out in text order and a workgroup works
     // through its chunks in order, so a chunk only ever waits for smaller chunks held by workgroups that
-    // are running.  (One counter bumped for every chunk is a single address, which the memory side updates
-    // some 90 million times a second: with 12 KiB chunks that rate is what bounds this kernel.  Two chunks
-    // per ticket lift the bound but lengthen the look-back by more than they gain, and reading two
-    // counters to bump the one that is behind costs three such accesses instead of one.)
+    // are running.  (Striping the chunks over eight ticket counters, a workgroup serving the stripe
+    // blockIdx % 8, was measured and changes nothing: 2.51 ms either way for 100 M dump-style rows, so the
+    // one counter's update rate is not what bounds this kernel.  Two chunks per ticket lengthen the
+    // look-back by more than they gain.)
     if (tid == 0) s_ticket = (a.ablate & 128) ? (long long)(blockIdx.x + gridDim.x * round++) : (long long)atomicAdd(a.ticket, 1u);
     __syncthreads();
     const int64_t c_first = (int64_t)s_ticket * kIngPerTicket;
@@ -564,7 +586,7 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
           if (ing_data_row(c0, c1)) dmask |= 1ull << k;
           else if ((c0 | 0x20u) == 'i') {
             // (bytes past the end of the text: the sentinel newline stops the search)
-            const int at = ing_statement_row(s_chunk + o + k);
+            const int at = ing_statement_row(s_text, kIngFront + o + k);
             if (at >= 0) { dmask |= 1ull << k; stmt_at[n_stmt < 3 ? n_stmt : 2] = (unsigned short)(o + k + at); ++n_stmt; smask_stmt |= 1ull << k; }
           }
         }

@@ -425,8 +425,12 @@ def _check_any_order(motor, oracle, oid, pidx, qty, cust, base, c_n, price):
 
 @pytest.mark.parametrize("n,p,c,mode", [(1000, 100, 50, "shuffle"), (300_003, 10_000, 100_000, "shuffle"),
                                          (1_000_000, 10_000, 100_000, "interleave"), (2_000_000, 10_000, 100_000, "sorted"),
-                                         (700_001, 60_000, 3_000_000, "shuffle")])
+                                         (700_001, 60_000, 3_000_000, "shuffle"),
+                                         (20_000_003, 10_000, 100_000, "shuffle"), (20_000_003, 10_000, 100_000, "blocks")])
 def test_any_line_order(motor, oracle, n, p, c, mode):
+    """shuffle: every row somewhere else (the order-restoring path: at 20 M lines 306 buckets in 5 coarse bins);
+    interleave / sorted: near-grouped rows (the device picks the atomic kernel); blocks: runs of 3000 rows in a
+    random order (grouped inside a block, far from grouped overall)."""
     d = oracle.synth(n, p, c, zipf=1, qty_mode=1)
     oid, pidx, qty = d["order_id"], d["product_idx"], d["qty"]
     rng = np.random.default_rng(23)
@@ -437,6 +441,10 @@ def test_any_line_order(motor, oracle, n, p, c, mode):
         perm = np.arange(n)
         k = (n // 2) * 2
         perm[:k] = perm[:k].reshape(-1, 2)[:, ::-1].reshape(-1)
+    elif mode == "blocks":
+        k = n // 3000
+        perm = np.concatenate([(rng.permutation(k)[:, None] * 3000 + np.arange(3000)[None, :]).reshape(-1),
+                               np.arange(k * 3000, n)])
     else:
         perm = np.arange(n)
     _check_any_order(motor, oracle, oid[perm], pidx[perm], qty[perm], d["order_customer"], 5, c, oracle.synth_prices(p))
