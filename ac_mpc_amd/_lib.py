@@ -27,7 +27,7 @@ EXPORTS = (
 OK, E_INVALID, E_HIP, E_ALIGN, E_DATA, E_STATE, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
 ST_ORDER_RANGE, ST_ORDER_UNSORTED, ST_CUSTOMER_RANGE, ST_INGEST_MALFORMED, ST_INGEST_CAPACITY = 1, 2, 4, 8, 16
 ST_EMIT_CAPACITY, ST_INTERNAL = 32, 64
-EMIT_SQL, EMIT_CSV = 0, 1
+EMIT_SQL, EMIT_CSV, EMIT_DISPLAY = 0, 1, 2
 ORDER_COUNTS, DESCUENTO_UNITS, DESCUENTO_PERCENT = 1, 0, 1
 OPT_LINE_ORDER, ORDER_GROUPED, ORDER_ANY, ORDER_AUTO = 1, 0, 1, 2
 K_LINES, K_FIXUP, K_CUSTOMERS, K_CUSTMERGE, N_KERNELS = 0, 1, 2, 3, 4

@@ -1468,7 +1468,8 @@ int launch_emit(acmpc_ctx* ctx, const EmitArgs& a, hipStream_t st) {
 int emit_device_impl(acmpc_ctx* ctx, const char* who, int kind, const int64_t* d_value, int64_t n_rows,
                      int64_t order_id_base, int style, char* d_text, int64_t capacity, int64_t* d_n_bytes,
                      hipStream_t st) {
-  if (style != ACMPC_EMIT_SQL && style != ACMPC_EMIT_CSV) return fail(ctx, ACMPC_E_INVALID, "%s: unknown style %d", who, style);
+  if (style != ACMPC_EMIT_SQL && style != ACMPC_EMIT_CSV && !(style == ACMPC_EMIT_DISPLAY && kind == kEmitTotals))
+    return fail(ctx, ACMPC_E_INVALID, "%s: unknown style %d", who, style);
   if (n_rows < 0 || capacity < 0 || !d_n_bytes) return fail(ctx, ACMPC_E_INVALID, "%s: bad size or null byte counter", who);
   if (n_rows > 0 && !d_value) return fail(ctx, ACMPC_E_INVALID, "%s: null value pointer", who);
   if (capacity > 0 && !d_text) return fail(ctx, ACMPC_E_INVALID, "%s: null text pointer", who);
@@ -1491,6 +1492,7 @@ int emit_device_impl(acmpc_ctx* ctx, const char* who, int kind, const int64_t* d
     HIPCHK(ctx, hipMemsetAsync(d_n_bytes, 0, sizeof(int64_t), st));
     return ACMPC_OK;
   }
+  if (kind == kEmitTotals && style == ACMPC_EMIT_DISPLAY) return launch_emit<kEmitTotals, kEmitDisplay>(ctx, a, st);
   if (kind == kEmitTotals)
     return style == ACMPC_EMIT_SQL ? launch_emit<kEmitTotals, kEmitSql>(ctx, a, st) : launch_emit<kEmitTotals, kEmitCsv>(ctx, a, st);
   return style == ACMPC_EMIT_SQL ? launch_emit<kEmitStock, kEmitSql>(ctx, a, st) : launch_emit<kEmitStock, kEmitCsv>(ctx, a, st);

@@ -18,7 +18,7 @@ constexpr int kEmitMaxRow = 104;          // longest row of any kind and style, 
 constexpr uint32_t kStEmitCapacity = 32u;
 
 constexpr int kEmitTotals = 0, kEmitStock = 1;
-constexpr int kEmitSql = 0, kEmitCsv = 1;
+constexpr int kEmitSql = 0, kEmitCsv = 1, kEmitDisplay = 2;
 
 struct EmitArgs {
   const long long* value;               // order_total_cents[n_rows] or product_qty[n_rows]
@@ -92,6 +92,33 @@ __device__ __forceinline__ int emit_put_amount(unsigned char* s, int p, long lon
   return p + 3;
 }
 
+// [-]u,uuu,uuu.cc: number_format($suma, 2) of process/carrito.php:19 (comma between groups of three
+// digits, '.' before the cents) for an amount held exactly in cents
+__device__ __forceinline__ int emit_grouped_len(long long cents) {
+  const int nd = emit_digits(emit_abs(cents) / 100ull);
+  return (cents < 0) + nd + (nd - 1) / 3 + 3;
+}
+
+__device__ __forceinline__ int emit_put_grouped(unsigned char* s, int p, long long cents) {
+  const unsigned long long m = emit_abs(cents);
+  unsigned long long units = m / 100ull;
+  const uint32_t frac = (uint32_t)(m - units * 100ull);
+  if (cents < 0) s[p++] = '-';
+  const int nd = emit_digits(units);
+  int end = p + nd + (nd - 1) / 3;                       // one past the last digit of the units
+  const int after = end;
+  for (int k = 0; k < nd; ++k) {
+    if (k && k % 3 == 0) s[--end] = ',';
+    const unsigned long long q = units / 10ull;
+    s[--end] = (unsigned char)('0' + (uint32_t)(units - q * 10ull));
+    units = q;
+  }
+  s[after] = '.';
+  s[after + 1] = (unsigned char)('0' + frac / 10u);
+  s[after + 2] = (unsigned char)('0' + frac % 10u);
+  return after + 3;
+}
+
 __device__ __forceinline__ int emit_int_len(long long v) { return (v < 0) + emit_digits(emit_abs(v)); }
 
 __device__ __forceinline__ int emit_put_int(unsigned char* s, int p, long long v) {
@@ -146,6 +173,18 @@ struct EmitRow<kEmitTotals, kEmitCsv> {
     s[p++] = ',';
     p = emit_put_amount(s, p, a.value[r]);
     s[p] = '\n';
+  }
+};
+
+// The fragment process/carrito.php:19 echoes for a cart, one line per order:
+//   <tr><td>Subtotal</td><td>$2,200.00</td></tr>
+template <>
+struct EmitRow<kEmitTotals, kEmitDisplay> {
+  static __device__ __forceinline__ int len(const EmitArgs& a, int64_t r) { return 26 + emit_grouped_len(a.value[r]) + 11; }
+  static __device__ __forceinline__ void put(const EmitArgs& a, int64_t r, unsigned char* s, int p) {
+    p = emit_put_lit(s, p, "<tr><td>Subtotal</td><td>$");
+    p = emit_put_grouped(s, p, a.value[r]);
+    emit_put_lit(s, p, "</td></tr>\n");
   }
 };
 

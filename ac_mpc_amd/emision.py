@@ -17,7 +17,7 @@ import numpy as np
 from . import _lib
 from .lote import ErrorLote, MotorLote
 
-SQL, CSV = _lib.EMIT_SQL, _lib.EMIT_CSV
+SQL, CSV, VISTA = _lib.EMIT_SQL, _lib.EMIT_CSV, _lib.EMIT_DISPLAY     # VISTA: the subtotal fragment of process/carrito.php:19
 MAX_FILA_TOTALES, MAX_FILA_STOCK = 83, 103
 
 

@@ -240,6 +240,22 @@ class consultasLote {
         return FFI::string($out, $len->cdata);
     }
 
+    /*
+     * The line process/carrito.php:19 echoes for a cart, for every order:
+     * "<tr><td>Subtotal</td><td>$2,200.00</td></tr>" (number_format($suma, 2) of the total).
+     */
+    public static function FilasSubtotal($TotalPagar) {
+        self::conectar();
+        $m = count($TotalPagar);
+        $tot = self::columna("int64_t", $TotalPagar);
+        $cap = max(70 * $m, 1);
+        $out = self::$ffi->new("char[$cap]");
+        $len = self::$ffi->new("int64_t");
+        self::comprobar(self::$ffi->acmpc_emit_totals(self::$ctx, $tot, $m, 0, 2 /* ACMPC_EMIT_DISPLAY */, $out, $cap, FFI::addr($len)),
+                        "escribir subtotales");
+        return FFI::string($out, $len->cdata);
+    }
+
     /* "update producto set Stock=Stock-3 where CodigoProd='1';" for every product with a non-zero delta. */
     public static function SentenciasStock($DeltaStock) {
         self::conectar();

@@ -400,6 +400,10 @@ int acmpc_ingest_detalle(acmpc_ctx* ctx, const char* text, int64_t n_bytes,
  *
  *   totals, ACMPC_EMIT_SQL   update venta set TotalPagar='2200.00' where NumPedido='5';\n
  *   totals, ACMPC_EMIT_CSV   5,2200.00\n
+ *   totals, ACMPC_EMIT_DISPLAY   <tr><td>Subtotal</td><td>$2,200.00</td></tr>\n
+ *                            the fragment process/carrito.php:19 echoes for a cart: number_format($suma, 2),
+ *                            i.e. a comma between groups of three digits and '.' before the cents; one
+ *                            line per order, in order-index order (totals only)
  *   stock,  ACMPC_EMIT_SQL   update producto set Stock=Stock-3 where CodigoProd='1';\n
  *                            (Stock=Stock+3 when the delta is negative)
  *   stock,  ACMPC_EMIT_CSV   1,3\n                    (code, signed delta)
@@ -413,6 +417,7 @@ int acmpc_ingest_detalle(acmpc_ctx* ctx, const char* text, int64_t n_bytes,
  * ---------------------------------------------------------------------- */
 #define ACMPC_EMIT_SQL 0
 #define ACMPC_EMIT_CSV 1
+#define ACMPC_EMIT_DISPLAY 2
 #define ACMPC_ST_EMIT_CAPACITY 32u /* acmpc_emit_*: the text needs more than capacity_bytes */
 
 /* Write the audit rows of n_orders DEVICE totals into DEVICE text (16-byte aligned) of

@@ -27,6 +27,21 @@ static int amount(char* dst, int64_t cents)
   return sprintf(dst, "%s%" PRIu64 ".%02u", cents < 0 ? "-" : "", m / 100u, (unsigned)(m % 100u));
 }
 
+/* number_format($suma, 2) of process/carrito.php:19 for an amount held exactly in cents. */
+static int grouped(char* dst, int64_t cents)
+{
+  char digits[32];
+  uint64_t m = mag(cents);
+  int nd = sprintf(digits, "%" PRIu64, m / 100u), n = 0;
+  if (cents < 0) dst[n++] = '-';
+  for (int i = 0; i < nd; ++i) {
+    if (i && (nd - i) % 3 == 0) dst[n++] = ',';
+    dst[n++] = digits[i];
+  }
+  n += sprintf(dst + n, ".%02u", (unsigned)(m % 100u));
+  return n;
+}
+
 /* Appends n bytes of src at offset *pos if they fit; always advances *pos. */
 static void put(char* out, int64_t cap, int64_t* pos, const char* src, int n)
 {
@@ -35,7 +50,8 @@ static void put(char* out, int64_t cap, int64_t* pos, const char* src, int n)
   *pos += n;
 }
 
-/* style 0: SQL update statements, 1: CSV.  Returns the bytes the full text needs. */
+/* style 0: SQL update statements, 1: CSV, 2: the subtotal fragment of process/carrito.php:19.  Returns the
+ * bytes the full text needs. */
 ORACLE_API int64_t oracle_emit_totals(const int64_t* total_cents, int64_t n_orders, int32_t order_id_base, int style,
                                       char* out, int64_t capacity)
 {
@@ -44,8 +60,10 @@ ORACLE_API int64_t oracle_emit_totals(const int64_t* total_cents, int64_t n_orde
   for (int64_t i = 0; i < n_orders; ++i) {
     amount(am, total_cents[i]);
     int64_t id = (int64_t)order_id_base + i;
-    int n = style == 0 ? sprintf(row, "update venta set TotalPagar='%s' where NumPedido='%" PRId64 "';\n", am, id)
-                       : sprintf(row, "%" PRId64 ",%s\n", id, am);
+    int n;
+    if (style == 2) { char g[48]; g[grouped(g, total_cents[i])] = 0; n = sprintf(row, "<tr><td>Subtotal</td><td>$%s</td></tr>\n", g); }
+    else n = style == 0 ? sprintf(row, "update venta set TotalPagar='%s' where NumPedido='%" PRId64 "';\n", am, id)
+                        : sprintf(row, "%" PRId64 ",%s\n", id, am);
     put(out, capacity, &pos, row, n);
   }
   return pos;

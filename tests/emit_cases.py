@@ -10,7 +10,15 @@ def amount(c: int) -> str:
     return f"{'-' if c < 0 else ''}{m // 100}.{m % 100:02d}"
 
 
+def grouped(c: int) -> str:
+    """number_format($suma, 2) of process/carrito.php:19 from integer cents (Python's own ',' grouping)."""
+    m = abs(int(c))
+    return f"{'-' if c < 0 else ''}{m // 100:,}.{m % 100:02d}"
+
+
 def totals_text(totals, base: int, style: int) -> bytes:
+    if style == 2:
+        return "".join(f"<tr><td>Subtotal</td><td>${grouped(t)}</td></tr>\n" for t in totals).encode()
     if style == 0:
         return "".join(f"update venta set TotalPagar='{amount(t)}' where NumPedido='{base + i}';\n" for i, t in enumerate(totals)).encode()
     return "".join(f"{base + i},{amount(t)}\n" for i, t in enumerate(totals)).encode()

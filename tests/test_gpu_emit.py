@@ -14,13 +14,13 @@ def em():
     return emision
 
 
-@pytest.mark.parametrize("style", [0, 1])
+@pytest.mark.parametrize("style", [0, 1, 2])
 def test_totals_edge_values(motor, oracle, em, style):
     vals = ec.edge_values()
     assert em.totales(motor, vals, 5, style) == oracle.emit_totals(vals, 5, style) == ec.totals_text(vals.tolist(), 5, style)
 
 
-@pytest.mark.parametrize("style", [0, 1])
+@pytest.mark.parametrize("style", [0, 1, 2])
 @pytest.mark.parametrize("n,base", [(1, 5), (255, 5), (256, -7), (257, 0), (4096, 999_990), (4097, -2147483648), (100_003, 2147383644)])
 def test_totals_sizes(motor, oracle, em, style, n, base):
     vals = ec.random_values(n, n)
