@@ -15,6 +15,14 @@ __global__ void __launch_bounds__(256) k_atom(unsigned long long* tab, unsigned 
     if (MODE == 1) atomicAdd(&tab32[c], (unsigned int)(h & 0xffff));
     if (MODE == 2) __hip_atomic_fetch_add(&tab[c], h & 0xffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (MODE == 3) tab[c] = h;   // plain scattered store, for scale
+    if (MODE == 4) atomicAdd(&tab[(size_t)(blockIdx.x & 7) * C + c], h & 0xffffff);   // one table per XCD label
+    if (MODE == 5) { if ((blockIdx.x & 7) == 0) atomicAdd(&tab[c], h & 0xffffff); }   // one XCD does an eighth of the adds
+    if (MODE == 6) {   // one table per XCD by the hardware's own id
+      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+      if (xcc != (blockIdx.x & 7)) tab32[(8u << 20) - 1] = 1;
+      atomicAdd(&tab[(size_t)xcc * C + c], h & 0xffffff);
+    }
+    if (MODE == 7) atomicAdd(&tab32[(size_t)(blockIdx.x & 7) * C + c], (unsigned int)(h & 0xffff));
   }
 }
 template <int MODE> void run(const char* name, unsigned long long* tab, unsigned int* t32, int C, long long m) {
@@ -36,6 +44,15 @@ int main() {
     run<1>("u32 atomicAdd (agent scope)", tab, t32, C, m);
     run<2>("u64 atomic add (workgroup scope)", tab, t32, C, m);
     run<3>("plain 8-byte scattered store", tab, t32, C, m);
+    if (C <= 1000000) {
+      run<4>("u64 atomicAdd, table per XCD label", tab, t32, C, m);
+      run<6>("u64 atomicAdd, table per XCC_ID", tab, t32, C, m);
+      run<7>("u32 atomicAdd, table per XCD label", tab, t32, C, m);
+    }
+    run<5>("u64 atomicAdd, 1/8 of adds, one XCD", tab, t32, C, m);
   }
+  unsigned int flag = 0;
+  CK(hipMemcpy(&flag, t32 + (8u << 20) - 1, 4, hipMemcpyDeviceToHost));
+  printf("blockIdx %% 8 == XCC_ID for every workgroup: %s\n", flag ? "NO" : "yes");
   return 0;
 }
