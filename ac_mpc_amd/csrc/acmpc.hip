@@ -1387,7 +1387,8 @@ ACMPC_API int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, in
   a.n_bytes = n_bytes;
   a.n_chunks = (n_bytes + kIngChunk - 1) / kIngChunk;
   int rc;
-  if ((rc = ensure(ctx, ctx->d_chunk_rows, (size_t)a.n_chunks + 1))) return rc;
+  constexpr size_t kTicketWords64 = (size_t)kIngStripes * kIngTicketPitch / 2;    // the ticket counters, behind the entries
+  if ((rc = ensure(ctx, ctx->d_chunk_rows, (size_t)a.n_chunks + kTicketWords64))) return rc;
   a.chunk_state = ctx->d_chunk_rows.p;
   a.ticket = reinterpret_cast<unsigned int*>(ctx->d_chunk_rows.p + a.n_chunks);
   a.dict = ctx->d_dict.p; a.dict_disp = ctx->d_dict_disp.p; a.dict_mask = ctx->dict_mask;
@@ -1404,9 +1405,10 @@ ACMPC_API int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, in
     HIPCHK(ctx, hipMemsetAsync(d_n_rows, 0, sizeof(int64_t), st));
     return ACMPC_OK;
   }
-  // entries and ticket start at zero; chunks are handed out in order, so any grid size is safe
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_chunk_rows.p, 0, ((size_t)a.n_chunks + 1) * 8, st));
+  // entries and tickets start at zero
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_chunk_rows.p, 0, ((size_t)a.n_chunks + kTicketWords64) * 8, st));
   const int blocks = (int)std::min<int64_t>(a.n_chunks, (int64_t)ctx->n_cu * kIngBlocksPerCu);
+  a.n_stripes = std::min(blocks, kIngStripes);
   hipLaunchKernelGGL(k_ingest_parse, dim3(blocks), dim3(kIngThreads), 0, st, a);
   HIPCHK(ctx, hipGetLastError());
   return ACMPC_OK;

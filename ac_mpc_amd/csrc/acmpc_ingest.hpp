@@ -7,10 +7,12 @@
 // separated rows.  The grammar is spelled out in include/acmpc.h.
 //
 // One pass over the text (byte work; no MFMA):
-//   k_ingest_parse   12 KiB chunks are handed out in order; every chunk is staged in LDS (plus 128 bytes of lookahead); each thread finds
-//                    the row starts in its 48 bytes and ranks them with a block scan; the rows are
-//                    then handed out one per thread, run through a table-driven automaton, converted,
-//                    looked up in a hash dictionary of the product codes and written as columns
+//   k_ingest_parse   12 KiB chunks are handed out in text order (a ticket counter per stripe of chunks); a chunk
+//                    is staged in LDS (plus 256 bytes of look-ahead), every thread finds the rows that start
+//                    in its own 48 bytes and parses them itself: a table-driven automaton over the row,
+//                    word-wide number conversion, a perfect-hash dictionary of the product codes, and the
+//                    three columns written at the row's rank in the text (chunk counts are published and
+//                    summed by decoupled look-back; there is no counting pass)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,7 +24,8 @@ constexpr int kIngThreads = 256;
 constexpr int kIngPerThread = 48;                       // bytes of text per thread (a multiple of 16)
 constexpr int kIngChunk = kIngThreads * kIngPerThread;  // 12 KiB per workgroup iteration
 constexpr int kIngWords = kIngPerThread / 4;
-constexpr int kIngPerTicket = 1;                        // consecutive chunks a workgroup takes at once
+constexpr int kIngStripes = 8;                          // chunk c belongs to stripe c % n_stripes; a counter per stripe
+constexpr int kIngTicketPitch = 64;                     // 32-bit words between two counters: a line of their own each
 constexpr int kIngBlocksPerCu = 5;                      // resident workgroups per CU (LDS and registers allow five)
 constexpr int kIngLook = 256;                           // lookahead kept in LDS: a statement's row may start 100 bytes
                                                         // into its line, and the automaton looks at 128 bytes from there
@@ -37,7 +40,8 @@ struct IngestArgs {
   int64_t n_bytes;
   int64_t n_chunks;
   unsigned long long* chunk_state;    // [n_chunks] zero on entry: see ing_row_base
-  unsigned int* ticket;               // zero on entry: next group of kIngPerTicket chunks to hand out
+  unsigned int* ticket;               // zero on entry: kIngStripes counters, kIngTicketPitch words apart
+  int32_t n_stripes;                  // stripes in use (fewer than kIngStripes when there are fewer workgroups)
   const IngSlot* dict;            // perfect-hash dictionary of the product codes: one slot per probe
   const unsigned short* dict_disp;       // displacement of every bucket
   uint32_t dict_mask, dict_seed, dict_bucket_shift;
@@ -50,7 +54,8 @@ struct IngestArgs {
   long long* n_rows;                  // device scalar: data rows found
   unsigned long long* n_malformed;    // device scalar
   uint32_t* status;
-  int32_t ablate;                     // developer switch for timing experiments (0 in production)
+  int32_t ablate;                     // developer switch for timing experiments (0 in production): 1 no field
+                                      // conversion, 2 no dictionary, 4 no automaton, 8 no stores, 64 no look-back
 };
 
 __device__ __forceinline__ bool ing_digit(uint32_t c) { return c - '0' < 10u; }
@@ -146,51 +151,46 @@ __device__ __forceinline__ void ing_publish_own(unsigned long long* state, long 
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Called by one whole wave, after ing_publish_own.  Returns the number of data rows in chunks [0, c)
-// and publishes the chunk's inclusive prefix.
+// The entry that lane `lane` looks at in the first round of chunk c's look-back: the one at distance `lane`
+// in front of c - 1.  Issued early, the load is on its way while the wave does something else.
+__device__ __forceinline__ unsigned long long ing_look_first(const unsigned long long* state, long long c, int lane) {
+  const long long idx = c - 1 - lane;
+  return idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kIngInclusive;
+}
+
+// Called by a whole wave, after ing_publish_own.  Returns the number of data rows in chunks [0, c) and
+// publishes the chunk's inclusive prefix.  `first` is ing_look_first(state, c, lane).  Every round looks at
+// the 64 entries behind p (nearest first), one per lane: wider rounds were measured and cost more than
+// they save, every poll competes with the publishers for the same lines.
 __device__ __forceinline__ long long ing_row_base(unsigned long long* state, long long c, long long n_r, int lane,
-                                                  uint32_t* status) {
+                                                  uint32_t* status, unsigned long long first) {
   if (c == 0) return 0;
   long long excl = 0;
   long long p = c - 1;                                   // nearest predecessor not yet added
-  constexpr int kPer = 1;                                // entries per lane and round
+  bool preloaded = true;
   for (uint32_t polls = 0;;) {
-    // lane l looks at the entries at distance 8l .. 8l+7 behind p (nearest first)
-    unsigned long long v[kPer];
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-      const long long idx = p - ((long long)lane * kPer + j);
-      v[j] = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                      : kIngInclusive;                   // in front of chunk 0: nothing
-    }
-    int fj = kPer;                                       // this lane's nearest inclusive entry
-#pragma unroll
-    for (int j = kPer - 1; j >= 0; --j) fj = (v[j] >> 62) == 2ull ? j : fj;
-    const unsigned long long incl_mask = __ballot(fj < kPer);
-    const int first = incl_mask ? __ffsll((long long)incl_mask) - 1 : 64;     // lane holding the nearest one
+    const long long idx = p - lane;
+    const unsigned long long v = preloaded ? first
+                                 : (idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                             : kIngInclusive);                   // in front of chunk 0: nothing
+    preloaded = false;
+    const unsigned long long incl_mask = __ballot((v >> 62) == 2ull);
+    const int nearest = incl_mask ? __ffsll((long long)incl_mask) - 1 : 64;      // lane holding the nearest prefix
     // entries nearer than (and including) that one must all be published
-    const int upto = lane < first ? kPer - 1 : (lane == first ? fj : -1);
-    bool waiting = false;
-    long long val = 0;
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-      if (j <= upto) {
-        waiting |= (v[j] >> 62) == 0ull;
-        val += (long long)(v[j] & kIngValue);
-      }
-    }
-    if (__ballot(waiting)) {                             // a predecessor has not published yet
+    const bool mine = lane <= nearest;
+    if (__ballot(mine && (v >> 62) == 0ull)) {             // a predecessor has not published yet
       if (++polls > (1u << 24)) { if (lane == 0) atomicOr(status, kStInternal); break; }   // never expected
       // back off: every poll reads lines that the publishers are about to write, and the memory side
       // serves one address only so often
       if (polls < 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
       continue;
     }
+    long long val = mine ? (long long)(v & kIngValue) : 0ll;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) val += __shfl_xor(val, d);
     excl += val;
     if (incl_mask) break;
-    p -= 64 * kPer;
+    p -= 64;
   }
   if (lane == 0)
     __hip_atomic_store(&state[c], kIngInclusive | (unsigned long long)(excl + n_r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -401,9 +401,11 @@ __device__ __forceinline__ unsigned long long ing_digits_value(const unsigned ch
 // table look-ups of one row depend on each other; stepping several rows together fills the waits.
 template <int N>
 __device__ __forceinline__ void ing_scan_rows(const unsigned char* s_text, const unsigned char* s_ct, const uint2* s_T,
-                                              const int (&p)[N], uint32_t (&st16)[N], uint32_t (&A)[N], uint32_t (&B)[N]) {
+                                              const int (&p)[N], const bool (&have)[N], uint32_t (&st16)[N],
+                                              uint32_t (&A)[N], uint32_t (&B)[N]) {
+  // a lane without a row starts in the final state, which stays where it is and counts nothing
 #pragma unroll
-  for (int q = 0; q < N; ++q) { st16[q] = sStart * kNumClasses; A[q] = 0; B[q] = 0; }
+  for (int q = 0; q < N; ++q) { st16[q] = (have[q] ? sStart : sDone) * kNumClasses; A[q] = 0; B[q] = 0; }
   for (int j0 = 0; j0 < kIngSteps; j0 += 4) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -473,215 +475,274 @@ __device__ __forceinline__ bool ing_finish_row(const unsigned char* s_text, int 
   return ok;
 }
 
+// Inclusive prefix sum of a small integer over the 64 lanes in DPP adds (no LDS traffic).
+__device__ __forceinline__ int ing_wave_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+// Sixteen bytes of text at offset `off`.  A piece that reaches past the end of the text is put together
+// byte by byte: the byte at n_bytes is the sentinel newline (every row ends in one), bytes past it are 0.
+__device__ __forceinline__ uint4 ing_load_piece(const unsigned char* text, int64_t off, int64_t n_bytes) {
+  if (off + 16 <= n_bytes) return *reinterpret_cast<const uint4*>(text + off);
+  uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    uint32_t c = 0u;
+    if (off + b < n_bytes) c = text[off + b];
+    else if (off + b == n_bytes) c = (uint32_t)'\n';
+    w[b >> 2] |= c << (8 * (b & 3));
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Bit k set: byte k of the thread's 48 bytes (twelve little-endian words) is not a newline.  Per word the
+// exact zero-byte test leaves one flag in bit 7 of every byte; three shift-or steps bring the four flags
+// together in the top nibble, and a funnel shift appends the nibble to the mask (words are taken last to
+// first, so that word 0 ends in the lowest bits).
+__device__ __forceinline__ uint32_t ing_not_newline_nibble(uint32_t w) {
+  const uint32_t x = w ^ 0x0A0A0A0Au;
+  const uint32_t u = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;   // bit 7 of a byte: it is not '\n'
+  uint32_t acc = (u << 21) | u;
+  acc = (u << 14) | acc;
+  acc = (u << 7) | acc;
+  return acc;                                                                // flags of bytes 0..3 in bits 28..31
+}
+__device__ __forceinline__ unsigned long long ing_newline_mask(const uint32_t (&w)[kIngWords]) {
+  static_assert(kIngWords == 12, "two mask words: bytes 0..31 and 32..47");
+  uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+  for (int j = kIngWords - 1; j >= 8; --j) hi = __builtin_amdgcn_alignbit(hi, ing_not_newline_nibble(w[j]), 28);
+#pragma unroll
+  for (int j = 7; j >= 0; --j) lo = __builtin_amdgcn_alignbit(lo, ing_not_newline_nibble(w[j]), 28);
+  return ((unsigned long long)(~hi & 0xffffu) << 32) | (unsigned long long)~lo;
+}
+
+// What a thread knows about the data rows that start in its 48 bytes of a chunk.
+struct IngOwn {
+  unsigned long long rows;    // bit k: a data row starts at byte k of the slice (for a statement line: the line)
+  uint32_t stmt_at;           // statement lines (the ones that start with a letter): offsets of their '(' from the
+                              // line start, where the row starts; one byte each, in text order
+  int first;                  // rank of the thread's first row among the rows of the chunk
+};
+
+constexpr int kIngBuf = kIngFront + kIngChunk + kIngLook + 64;
+
+// Every thread owns 48 bytes of a 12 KiB chunk and parses the rows that START there (a row of the shapes the
+// reference writes takes 19..26 bytes, so a thread has one to three of them; any other mix only changes how
+// evenly the lanes are loaded).  A workgroup works on two chunks at a time: chunk i + 1 is staged in LDS,
+// its rows are found, counted and the count published, and only then is chunk i — staged one round earlier
+// in the other text buffer — parsed and written, because its first output row is the sum of the counts
+// of all chunks before it, and looking back over them is cheapest when it is done late.  The text of chunk
+// i + 2 is requested before the parse and waits in registers; so does the ticket after it.
 __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_eu(kIngBlocksPerCu * kIngThreads / 256, kIngBlocksPerCu * kIngThreads / 256))) k_ingest_parse(IngestArgs a) {
   // [16 bytes of slack][chunk][look-ahead][slack]: number and code windows may reach a few bytes outside a row
-  __shared__ __align__(16) unsigned char s_text[kIngFront + kIngChunk + kIngLook + 64];
-  // start offsets of the chunk's data rows, in text order (a data row takes at least two bytes)
-  __shared__ __align__(16) unsigned short s_row[kIngChunk / 2];
-  constexpr int kKeep = kIngChunk / 16;                    // parsed rows a chunk can park in LDS
-  static_assert(kIngChunk / 2 * 2 >= kKeep * 2 + 3 * kKeep * 4, "parsed columns are parked behind the row list");
+  __shared__ __align__(16) unsigned char s_text[2][kIngBuf];
   __shared__ __align__(8) uint2 s_T[kIngTableWords];
   __shared__ unsigned char s_ct[256];
   __shared__ int s_w[kIngThreads / 64];
-  __shared__ long long s_base;
-  __shared__ long long s_ticket;
+  __shared__ long long s_tk[2];
+  __shared__ long long s_base[2], s_base_of[2];            // row base of a chunk, and which chunk (+ 1) it belongs to
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < kIngTableWords; i += kIngThreads) {
     const unsigned long long e = a.tables[i];
     s_T[i] = make_uint2((uint32_t)e, (uint32_t)(e >> 32));
   }
   if (tid < 256) s_ct[tid] = reinterpret_cast<const unsigned char*>(a.tables + kIngTableWords)[tid];
-  if (tid < kIngFront) s_text[tid] = 0;
-  unsigned char* s_chunk = s_text + kIngFront;
-  unsigned long long bad = 0;
-  unsigned round = 0;                                      // (timing experiments only)
-  int32_t* s_res = reinterpret_cast<int32_t*>(s_row + kKeep);   // parked columns: [oid | pidx | qty], kKeep each
+  if (tid < kIngFront) { s_text[0][tid] = 0; s_text[1][tid] = 0; }
+  if (tid < 2) s_base_of[tid] = 0;
+  uint32_t bad = 0;                                        // malformed rows met by this thread (a chunk holds < 2^13 rows)
+  const int o = tid * kIngPerThread;                       // this thread's slice inside a chunk
 
-  // The first output row of chunk c (n_r data rows) comes from its predecessors' counts.  One wave looks
-  // back; the last chunk also knows the total.
-  auto resolve_base = [&](long long c, int n_r) {
-    if (wave == 0) {
-      const long long excl = (a.ablate & 64) ? c * 400 : ing_row_base(a.chunk_state, c, n_r, lane, a.status);
-      if (lane == 0) {
-        s_base = excl;
-        if (c == a.n_chunks - 1) {
-          *a.n_rows = excl + n_r;
-          if (excl + n_r > a.capacity) atomicOr(a.status, kStIngestCapacity);
-        }
-      }
-    }
-    __syncthreads();
+  // text of a chunk on its way to LDS: the thread's own 48 bytes, a piece of the look-ahead (the first
+  // kIngLook / 16 threads) and the byte in front of the chunk (thread 0)
+  uint4 rt[kIngPerThread / 16], rl;
+  uint32_t rprev = (uint32_t)'\n';
+  auto request_text = [&](int64_t c) {
+    const int64_t cbase = c * kIngChunk;
+#pragma unroll
+    for (int j = 0; j < kIngPerThread / 16; ++j) rt[j] = ing_load_piece(a.text, cbase + o + 16 * j, a.n_bytes);
+    if (tid < kIngLook / 16) rl = ing_load_piece(a.text, cbase + kIngChunk + 16 * tid, a.n_bytes);
+    if (tid == 0) rprev = c > 0 ? (uint32_t)a.text[cbase - 1] : (uint32_t)'\n';
   };
-  // Looking back is cheapest when it is done late (the predecessors have had time to publish), so a
-  // chunk's parsed columns are parked in LDS and written out only after the NEXT chunk of this workgroup
-  // has been staged, ranked and published.  (Every thread parks and reads back the same rows.)
-  long long c_parked = -1;
-  int n_parked = 0;
-  auto flush_parked = [&]() {                              // uniform
-    if (c_parked < 0) return;
-    resolve_base(c_parked, n_parked);
-    const long long rbase = s_base;
-    for (int r = tid; r < n_parked; r += kIngThreads) {
-      const long long row = rbase + r;
-      if (row < a.capacity && !(a.ablate & 8)) { a.order_id[row] = s_res[r]; a.product_idx[row] = s_res[kKeep + r]; a.qty[row] = s_res[2 * kKeep + r]; }
-    }
-    c_parked = -1;
+  // Chunks are handed out in text order within a stripe: stripe s = blockIdx % n_stripes owns the chunks
+  // c with c % n_stripes == s, and its workgroups draw them from a counter of their own.  (All workgroups
+  // drawing from one counter are served one after the other by the memory side, 11 ns apiece: 2.4 ms for
+  // the 213 k chunks of 100 M rows, whatever else the kernel does.)  A chunk waits only for chunks in front
+  // of it; the first of those that is unfinished is either being worked on or is the next ticket of its
+  // stripe, and workgroups are started in index order, so every stripe has a running workgroup to draw it.
+  const int stripe = (int)(blockIdx.x % (unsigned)a.n_stripes);
+  auto take_ticket = [&]() -> long long {
+    return (long long)atomicAdd(a.ticket + kIngTicketPitch * stripe, 1u) * a.n_stripes + stripe;
   };
+
+  if (tid == 0) s_tk[0] = take_ticket();
+  __syncthreads();
+  int64_t c_next = s_tk[0];
+  if (c_next >= a.n_chunks) return;                        // uniform
+  request_text(c_next);
+  long long tk_pending = 0;
+  if (tid == 0) tk_pending = take_ticket();
+  int64_t c_cur = -1;
+  int buf = 0, par = 1;                                    // text buffer and ticket slot of the chunk being staged
+  IngOwn cur = {0ull, 0u, 0}, nxt = {0ull, 0u, 0};
+  int n_cur = 0;
 
   for (;;) {
-    // A ticket is kIngPerTicket consecutive chunks.  Tickets go out in text order and a workgroup works
-    // through its chunks in order, so a chunk only ever waits for smaller chunks held by workgroups that
-    // are running.  (Striping the chunks over eight ticket counters, a workgroup serving the stripe
-    // blockIdx % 8, was measured and changes nothing: 2.51 ms either way for 100 M dump-style rows, so the
-    // one counter's update rate is not what bounds this kernel.  Two chunks per ticket lengthen the
-    // look-back by more than they gain.)
-    if (tid == 0) s_ticket = (a.ablate & 128) ? (long long)(blockIdx.x + gridDim.x * round++) : (long long)atomicAdd(a.ticket, 1u);
+    __syncthreads();                                       // the rows parsed last round have been read out of s_text[buf]
+    unsigned long long nl = 0;
+    if (c_next >= 0) {                                     // uniform
+      unsigned char* t = s_text[buf] + kIngFront;
+      uint32_t w[kIngWords];
+#pragma unroll
+      for (int j = 0; j < kIngPerThread / 16; ++j) {
+        *reinterpret_cast<uint4*>(t + o + 16 * j) = rt[j];
+        w[4 * j] = rt[j].x; w[4 * j + 1] = rt[j].y; w[4 * j + 2] = rt[j].z; w[4 * j + 3] = rt[j].w;
+      }
+      if (tid < kIngLook / 16) *reinterpret_cast<uint4*>(t + kIngChunk + 16 * tid) = rl;
+      if (tid == 0) { t[-1] = (unsigned char)rprev; s_tk[par] = tk_pending; }
+      nl = ing_newline_mask(w);
+    }
     __syncthreads();
-    const int64_t c_first = (int64_t)s_ticket * kIngPerTicket;
-    if (c_first >= a.n_chunks) break;                      // uniform
-    for (int part = 0; part < kIngPerTicket; ++part) {
-      const int64_t c = c_first + part;
-      if (c >= a.n_chunks) break;                            // uniform
-      const int64_t cbase = c * kIngChunk;
-      // stage chunk + lookahead (16-byte pieces; the text buffer is padded by the host side)
-      const int64_t avail = a.n_bytes - cbase;
-      const int want = (int)(avail < kIngChunk + kIngLook ? avail : kIngChunk + kIngLook);
-      for (int o = tid * 16; o < want && !((a.ablate & 16) && c >= (int64_t)gridDim.x); o += kIngThreads * 16) {
-        if (o + 16 <= want) {
-          *reinterpret_cast<uint4*>(s_chunk + o) = *reinterpret_cast<const uint4*>(a.text + cbase + o);
-        } else {
-          for (int b = o; b < want; ++b) s_chunk[b] = a.text[cbase + b];
-        }
-      }
-      if (tid == 0) s_chunk[want] = (unsigned char)'\n';     // sentinel: every row ends in a newline
-      // the 16 bytes in front of the chunk come along (the first thread needs the byte before its slice)
-      if (tid == kIngThreads - 1 && c > 0) *reinterpret_cast<uint4*>(s_text) = *reinterpret_cast<const uint4*>(a.text + cbase - kIngFront);
-      __syncthreads();
-      const int64_t base = cbase + (int64_t)tid * kIngPerThread;
-      // line starts in this thread's slice, then the data rows among them (first one or two bytes)
-      const int o = tid * kIngPerThread;
-      unsigned long long dmask = 0;
-      // statement lines of this slice (a statement line takes at least 20 bytes: at most three start here)
-      // hand out the position of their '(' instead of the line start
-      unsigned long long smask_stmt = 0;
-      unsigned short stmt_at[3] = {0, 0, 0};
+    if (c_next >= 0) {
+      // line starts of the slice (the byte in front is a newline, or the text starts here), then the data
+      // rows among them by their first one or two bytes; a statement line hands out the position of its '('
+      const unsigned char* t = s_text[buf] + kIngFront;
+      const int64_t left = a.n_bytes - (c_next * kIngChunk + o);      // bytes of text from this thread's first byte on
+      unsigned long long smask = ((nl << 1) | (t[o - 1] == (unsigned char)'\n' ? 1ull : 0ull)) & ((1ull << kIngPerThread) - 1ull);
+      if (left < kIngPerThread) smask = left > 0 ? (smask & ((1ull << left) - 1ull)) : 0ull;
+      nxt.rows = 0; nxt.stmt_at = 0;
       int n_stmt = 0;
-      if (base < a.n_bytes) {
-        uint32_t w[kIngWords];
-#pragma unroll
-        for (int j = 0; j < kIngWords / 4; ++j) {
-          // whole 16-byte pieces even at the end of the text: what lies past the last byte (the sentinel,
-          // leftovers of an earlier chunk) only sets mask bits that are cleared below
-          const uint4 v = *reinterpret_cast<const uint4*>(s_chunk + o + 16 * j);
-          w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
-        }
-        const uint32_t prev = base == 0 ? (uint32_t)'\n' : (uint32_t)s_chunk[o - 1];
-        unsigned long long smask = ing_line_start_mask(w, prev);
-        const int64_t left = a.n_bytes - base;                 // bytes of text from this thread's first byte on
-        if (left < kIngPerThread) smask &= (1ull << left) - 1ull;
-        for (unsigned long long m = smask; m; m &= m - 1ull) {
-          const int k = __ffsll((long long)m) - 1;
-          const uint32_t c0 = s_chunk[o + k];
-          const uint32_t c1 = k + 1 < left ? (uint32_t)s_chunk[o + k + 1] : 0u;
-          if (ing_data_row(c0, c1)) dmask |= 1ull << k;
-          else if ((c0 | 0x20u) == 'i') {
-            // (bytes past the end of the text: the sentinel newline stops the search)
-            const int at = ing_statement_row(s_text, kIngFront + o + k);
-            if (at >= 0) { dmask |= 1ull << k; stmt_at[n_stmt < 3 ? n_stmt : 2] = (unsigned short)(o + k + at); ++n_stmt; smask_stmt |= 1ull << k; }
+      for (unsigned long long m = smask; m; m &= m - 1ull) {
+        const int k = __ffsll((long long)m) - 1;
+        const uint32_t c0 = t[o + k];
+        const uint32_t c1 = k + 1 < left ? (uint32_t)t[o + k + 1] : 0u;
+        if (ing_data_row(c0, c1)) nxt.rows |= 1ull << k;
+        else if ((c0 | 0x20u) == 'i') {
+          // (bytes past the end of the text: the sentinel newline stops the search; a statement line takes
+          // at least 20 bytes, so at most three start in a slice)
+          const int at = ing_statement_row(s_text[buf], kIngFront + o + k);
+          if (at >= 0) {
+            nxt.rows |= 1ull << k;
+            nxt.stmt_at |= (uint32_t)at << (8 * (n_stmt < 3 ? n_stmt : 3));
+            ++n_stmt;
           }
         }
       }
-      const int cnt = __popcll(dmask);
-      // rank of this thread's first row inside the chunk
-      int incl = cnt;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+      const int cnt = __popcll(nxt.rows);
+      const int incl = ing_wave_scan(cnt);
       if (lane == 63) s_w[wave] = incl;
-      __syncthreads();
-      int woff = 0, n_r = 0;
+      nxt.first = incl - cnt;
+    }
+    __syncthreads();
+    int n_next = 0;
+    int64_t c_after = -1;
+    if (c_next >= 0) {
+      int woff = 0;
 #pragma unroll
-      for (int k = 0; k < kIngThreads / 64; ++k) { if (k < wave) woff += s_w[k]; n_r += s_w[k]; }
+      for (int k = 0; k < kIngThreads / 64; ++k) { if (k < wave) woff += s_w[k]; n_next += s_w[k]; }
+      nxt.first += woff;
       // publish as early as possible: successors add this count up long before this chunk knows its base
-      if (tid == 0 && !(a.ablate & 64)) ing_publish_own(a.chunk_state, c, n_r);
-      // a long row list would run into the parked columns of the chunk before: write those out first
-      if (n_r > kKeep) { flush_parked(); __syncthreads(); }  // (uniform) every thread has read its parked rows back
-      // hand the rows out one per thread: every lane of a wave then parses a row of its own, and
-      // consecutive lanes write consecutive output rows
-      int r = woff + incl - cnt;
-      {
-        int si = 0;
-        for (unsigned long long m = dmask; m; m &= m - 1ull, ++r) {
-          const int k = __ffsll((long long)m) - 1;
-          const bool stmt = (smask_stmt >> k) & 1ull;
-          s_row[r] = stmt ? stmt_at[si < 3 ? si : 2] : (unsigned short)(o + k);
-          si += stmt ? 1 : 0;
-        }
+      if (tid == 0 && !(a.ablate & 64)) ing_publish_own(a.chunk_state, c_next, n_next);
+      c_after = s_tk[par];
+      if (c_after < a.n_chunks) {
+        request_text(c_after);
+        if (tid == 0) tk_pending = take_ticket();
+      } else {
+        c_after = -1;
       }
-      __syncthreads();
-      if (n_r <= kKeep) {
-        flush_parked();                                      // the chunk before: its look-back comes late, after this publish
-        // A thread steps two rows through the automaton at once while more than one batch of rows is left
-        // (the table look-ups of a row depend on each other; a second row fills the waits), one otherwise.
-        auto parse_batch = [&](auto together, int r0) {
-          constexpr int kTogether = decltype(together)::value;
-          int p[kTogether];
-          uint32_t st16[kTogether], A[kTogether], B[kTogether];
-#pragma unroll
-          for (int q = 0; q < kTogether; ++q) {                // a missing row repeats the thread's first
-            const int rq = r0 + q * kIngThreads;
-            p[q] = kIngFront + (int)s_row[rq < n_r ? rq : r0];
-          }
-          if (a.ablate & 4) {
-#pragma unroll
-            for (int q = 0; q < kTogether; ++q) { st16[q] = sDone * kNumClasses; A[q] = 0x01000000u | (uint32_t)p[q]; B[q] = 0; }
-          } else {
-            ing_scan_rows<kTogether>(s_text, s_ct, s_T, p, st16, A, B);
-          }
-#pragma unroll
-          for (int q = 0; q < kTogether; ++q) {
-            const int rq = r0 + q * kIngThreads;
-            if (rq < n_r) {
-              int32_t oid = 0, pidx = -1, qty = 0;
-              // the cheaper conversion when no row of the wave has a long number or a long code
-              const uint32_t Aq = A[q];
-              const bool plain = ((Aq >> kANd1) & 127u) <= 8u && ((Aq >> kANd2) & 127u) <= 4u && ((Aq >> kACl) & 127u) <= 12u;
-              bool ok = true;
-              if (!(a.ablate & 1)) {
-                if (__ballot(!plain) == 0ull) ok = ing_finish_row<2, 1, 3>(s_text, p[q], st16[q], Aq, B[q], a, oid, pidx, qty);
-                else ok = ing_finish_row<3, 3, 8>(s_text, p[q], st16[q], Aq, B[q], a, oid, pidx, qty);
-              }
-              if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
-              s_res[rq] = oid; s_res[kKeep + rq] = pidx; s_res[2 * kKeep + rq] = qty;
+    }
+    if (c_cur >= 0) {
+      // Wave 0 looks back over the counts of the chunks in front and hands the row base to the other waves
+      // through LDS, where they wait for it (no barrier: wave 0 never waits for them, and polling LDS costs
+      // the memory side nothing).  The first round of its loads is issued here and used after the first rows
+      // have been through the automaton, which needs no row base.
+      unsigned long long look = kIngInclusive;
+      if (wave == 0 && !(a.ablate & 64)) look = ing_look_first(a.chunk_state, c_cur, lane);
+      auto row_base = [&]() -> long long {
+        long long rbase;
+        if (wave == 0) {
+          rbase = (a.ablate & 64) ? c_cur * 400 : ing_row_base(a.chunk_state, c_cur, n_cur, lane, a.status, look);
+          if (lane == 0) {
+            s_base[par] = rbase;
+            __hip_atomic_store(&s_base_of[par], c_cur + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (c_cur == a.n_chunks - 1) {
+              *a.n_rows = rbase + n_cur;
+              if (rbase + n_cur > a.capacity) atomicOr(a.status, kStIngestCapacity);
             }
           }
-        };
-        int b0 = 0;                                            // first row of the batch (uniform)
-        for (; n_r - b0 > kIngThreads; b0 += 2 * kIngThreads)
-          if (b0 + tid < n_r) parse_batch(std::integral_constant<int, 2>{}, b0 + tid);
-        if (b0 + tid < n_r) parse_batch(std::integral_constant<int, 1>{}, b0 + tid);
-        c_parked = c;
-        n_parked = n_r;
-      } else {
-        // more rows than can be parked (rows of a few bytes): look back first, write as they are parsed
-        resolve_base(c, n_r);
-        const long long rbase = s_base;
-        for (r = tid; r < n_r; r += kIngThreads) {
-          int32_t oid = 0, pidx = -1, qty = 0;
-          const int p[1] = {kIngFront + (int)s_row[r]};
-          uint32_t st16[1], A[1], B[1];
-          ing_scan_rows<1>(s_text, s_ct, s_T, p, st16, A, B);
-          const bool ok = ing_finish_row<3, 3, 8>(s_text, p[0], st16[0], A[0], B[0], a, oid, pidx, qty);
-          if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
-          const long long row = rbase + r;
-          if (row < a.capacity) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }
+        } else {
+          while (__hip_atomic_load(&s_base_of[par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != c_cur + 1)
+            __builtin_amdgcn_s_sleep(2);
+          rbase = s_base[par];
         }
-      }
-      __syncthreads();                                       // the text and the row list are free again
+        return rbase;
+      };
+      const unsigned char* tx = s_text[buf ^ 1];
+      unsigned long long m = cur.rows;
+      uint32_t at = cur.stmt_at;
+      long long row = -1;                                  // output row of the lane's next data row, once the base is known
+      auto take = [&](bool& have) -> int {
+        have = m != 0ull;
+        const int k = have ? __ffsll((long long)m) - 1 : 0;
+        int p = kIngFront + o + k;
+        if (have && at != 0u && (tx[p] | 0x20u) == (uint32_t)'i') { p += (int)(at & 0xffu); at >>= 8; }
+        m &= m - 1ull;
+        return p;
+      };
+      auto emit = [&](bool have, int p, uint32_t st16, uint32_t A, uint32_t B, bool wide) {
+        if (!have) return;
+        int32_t oid = 0, pidx = -1, qty = 0;
+        bool ok = true;
+        if (!(a.ablate & 1)) {
+          if (!wide) ok = ing_finish_row<2, 1, 3>(tx, p, st16, A, B, a, oid, pidx, qty);
+          else ok = ing_finish_row<3, 3, 8>(tx, p, st16, A, B, a, oid, pidx, qty);
+        }
+        if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
+        if (row < a.capacity && !(a.ablate & 8)) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }
+        ++row;
+      };
+      auto plain = [](uint32_t A) {
+        return ((A >> kANd1) & 127u) <= 8u && ((A >> kANd2) & 127u) <= 4u && ((A >> kACl) & 127u) <= 12u;
+      };
+      // two rows of the lane go through the automaton together while any lane has two left (the table
+      // look-ups of one row depend on each other; a second row fills the waits)
+      do {
+        bool have[2];
+        int p[2];
+        p[0] = take(have[0]);
+        p[1] = take(have[1]);
+        uint32_t st16[2], A[2], B[2];
+        const bool two = __ballot(have[1]) != 0ull;
+        if (a.ablate & 4) { st16[0] = st16[1] = sDone * kNumClasses; A[0] = A[1] = 0x01000000u; B[0] = B[1] = 0; }
+        else if (two) ing_scan_rows<2>(tx, s_ct, s_T, p, have, st16, A, B);
+        else {
+          const int p1[1] = {p[0]};
+          const bool h1[1] = {have[0]};
+          uint32_t s1[1], A1[1], B1[1];
+          ing_scan_rows<1>(tx, s_ct, s_T, p1, h1, s1, A1, B1);
+          st16[0] = s1[0]; A[0] = A1[0]; B[0] = B1[0];
+          st16[1] = sDone * kNumClasses; A[1] = 0; B[1] = 0;
+        }
+        if (row < 0) row = row_base() + cur.first;          // uniform: the first pass of this chunk
+        // the cheaper conversion when no row of the wave has a long number or a long code
+        const bool wide = __ballot((have[0] && !plain(A[0])) || (have[1] && !plain(A[1]))) != 0ull;
+        emit(have[0], p[0], st16[0], A[0], B[0], wide);
+        if (two) emit(have[1], p[1], st16[1], A[1], B[1], wide);
+      } while (__ballot(m != 0ull));
     }
+    if (c_next < 0) break;                                 // uniform: nothing was staged, the last chunk is written
+    c_cur = c_next; cur = nxt; n_cur = n_next;
+    c_next = c_after;
+    buf ^= 1; par ^= 1;
   }
-  flush_parked();
   if (bad) {
-    atomicAdd(a.n_malformed, bad);
+    atomicAdd(a.n_malformed, (unsigned long long)bad);
     atomicOr(a.status, kStIngestMalformed);
   }
 }

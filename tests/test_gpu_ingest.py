@@ -53,7 +53,7 @@ def test_edge_rows_on_device_match_hand_expectations(motor):
 
 
 @pytest.mark.parametrize("style", ["dump", "csv", "tsv_crlf", "quoted", "statements"])
-@pytest.mark.parametrize("n", [1, 63, 5000, 400_003])
+@pytest.mark.parametrize("n", [1, 63, 1500, 3900, 5000, 400_003])   # 1, 1, 3..6, 8..16, 10..21, ~800+ chunks of 12 KiB
 def test_styles_and_sizes(motor, oracle, style, n):
     d = oracle.synth(n, 10_000, 50, zipf=1, qty_mode=1)
     pidx = d["product_idx"].copy()
