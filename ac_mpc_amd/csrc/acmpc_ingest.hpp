@@ -264,8 +264,11 @@ constexpr int kIngFront = 16;                                // LDS bytes kept i
 
 // word A fields
 constexpr int kANd1 = 0, kANd2 = 7, kACl = 14, kANeg1 = 21, kANeg2 = 22, kALen = 23;
-// word B fields (bits 21..31 of the entry's low word hold 16 * next state)
+// word B fields (bits 21..31 of the entry's low word hold kStUnit * next state)
 constexpr int kBE1 = 0, kBCs = 7, kBE2 = 14, kBState = 21;
+// A state travels as its number times kStUnit: shifted left by four that is the byte offset of the state's
+// row of 16 eight-byte entries, to which the byte class, kept as its number times eight, is added.
+constexpr int kStUnit = 8;
 
 inline int ing_class_of(int c) {
   if (c >= '0' && c <= '9') return kcDig;
@@ -356,7 +359,7 @@ inline void ing_build_tables(unsigned long long* T, unsigned char* CT) {
         if (pre_code(s) && (in_a(n) || n == sAEnd || n == sBSp || n == sCQ1 || n == sCQ2)) b += 1ull << kBCs;
         if (n < sESp) b += 1ull << kBE2;
       }
-      b |= (unsigned long long)(n * kNumClasses) << kBState;
+      b |= (unsigned long long)(n * kStUnit) << kBState;
       T[s * kNumClasses + c] = (a << 32) | b;
     }
   }
@@ -400,27 +403,41 @@ __device__ __forceinline__ unsigned long long ing_digits_value(const unsigned ch
 // Run the automaton over N rows of this lane at once (they start at bytes p[0..N) of the LDS text).  The
 // table look-ups of one row depend on each other; stepping several rows together fills the waits.
 template <int N>
-__device__ __forceinline__ void ing_scan_rows(const unsigned char* s_text, const unsigned char* s_ct, const uint2* s_T,
-                                              const int (&p)[N], const bool (&have)[N], uint32_t (&st16)[N],
+__device__ __forceinline__ void ing_scan_rows(const unsigned char* s_text, const unsigned char* s_ct8, const uint2* s_T,
+                                              const int (&p)[N], const bool (&have)[N], uint32_t (&st)[N],
                                               uint32_t (&A)[N], uint32_t (&B)[N]) {
   // a lane without a row starts in the final state, which stays where it is and counts nothing
 #pragma unroll
-  for (int q = 0; q < N; ++q) { st16[q] = (have[q] ? sStart : sDone) * kNumClasses; A[q] = 0; B[q] = 0; }
+  for (int q = 0; q < N; ++q) { st[q] = (have[q] ? sStart : sDone) * kStUnit; A[q] = 0; B[q] = 0; }
+  const unsigned char* tab = reinterpret_cast<const unsigned char*>(s_T);
   for (int j0 = 0; j0 < kIngSteps; j0 += 4) {
+    // four bytes of every row and their classes first (none of these reads waits for a state), then the
+    // chain of table look-ups, which does
+    uint32_t cls8[N][4];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      uint32_t c[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[j] = s_text[p[q] + j0 + j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cls8[q][j] = s_ct8[c[j]];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
       for (int q = 0; q < N; ++q) {
-        const uint32_t cls = s_ct[s_text[p[q] + j0 + j]];
-        const uint2 e = s_T[st16[q] + cls];
+        const uint2 e = *reinterpret_cast<const uint2*>(tab + ((st[q] << 4) + cls8[q][j]));
         B[q] += e.x;
         A[q] += e.y;
-        st16[q] = e.x >> kBState;
+        st[q] = e.x >> kBState;
+        // (kept apart from the shift of the next look-up: folded together the two shifts need a mask and an
+        // add, three instructions where a shift and a shift-add do)
+        asm volatile("" : "+v"(st[q]));
       }
     }
     bool running = false;
 #pragma unroll
-    for (int q = 0; q < N; ++q) running |= st16[q] < (uint32_t)(sDone * kNumClasses);
+    for (int q = 0; q < N; ++q) running |= st[q] < (uint32_t)(sDone * kStUnit);
     if (__ballot(running) == 0ull) break;                  // every row of every active lane is done
   }
 }
@@ -435,7 +452,7 @@ __device__ __forceinline__ bool ing_finish_row(const unsigned char* s_text, int 
   const int nd1 = (A >> kANd1) & 127, nd2 = (A >> kANd2) & 127, cl = (A >> kACl) & 127, len = (A >> kALen) & 127;
   const bool neg1 = (A >> kANeg1) & 1u, neg2 = (A >> kANeg2) & 1u;
   const int e1 = (B >> kBE1) & 127, cs = (B >> kBCs) & 127, e2 = (B >> kBE2) & 127;
-  bool ok = st16 == (uint32_t)(sDone * kNumClasses) && len <= kIngMaxRow && nd1 <= 10 && nd2 <= 10 && cl <= 30;
+  bool ok = st16 == (uint32_t)(sDone * kStUnit) && len <= kIngMaxRow && nd1 <= 10 && nd2 <= 10 && cl <= 30;
   const unsigned long long v1 = ing_digits_value<W1>(s_text, p + e1, min(nd1, W1 == 3 ? 10 : 4 * W1));
   const unsigned long long v2 = ing_digits_value<W2>(s_text, p + e2, min(nd2, W2 == 3 ? 10 : 4 * W2));
   ok = ok && v1 <= (neg1 ? 2147483648ull : 2147483647ull) && v2 <= (neg2 ? 2147483648ull : 2147483647ull);
@@ -553,7 +570,7 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
     const unsigned long long e = a.tables[i];
     s_T[i] = make_uint2((uint32_t)e, (uint32_t)(e >> 32));
   }
-  if (tid < 256) s_ct[tid] = reinterpret_cast<const unsigned char*>(a.tables + kIngTableWords)[tid];
+  if (tid < 256) s_ct[tid] = (unsigned char)(8u * reinterpret_cast<const unsigned char*>(a.tables + kIngTableWords)[tid]);   // class * 8
   if (tid < kIngFront) { s_text[0][tid] = 0; s_text[1][tid] = 0; }
   if (tid < 2) s_base_of[tid] = 0;
   uint32_t bad = 0;                                        // malformed rows met by this thread (a chunk holds < 2^13 rows)
@@ -719,7 +736,7 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
         p[1] = take(have[1]);
         uint32_t st16[2], A[2], B[2];
         const bool two = __ballot(have[1]) != 0ull;
-        if (a.ablate & 4) { st16[0] = st16[1] = sDone * kNumClasses; A[0] = A[1] = 0x01000000u; B[0] = B[1] = 0; }
+        if (a.ablate & 4) { st16[0] = st16[1] = sDone * kStUnit; A[0] = A[1] = 0x01000000u; B[0] = B[1] = 0; }
         else if (two) ing_scan_rows<2>(tx, s_ct, s_T, p, have, st16, A, B);
         else {
           const int p1[1] = {p[0]};
@@ -727,7 +744,7 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
           uint32_t s1[1], A1[1], B1[1];
           ing_scan_rows<1>(tx, s_ct, s_T, p1, h1, s1, A1, B1);
           st16[0] = s1[0]; A[0] = A1[0]; B[0] = B1[0];
-          st16[1] = sDone * kNumClasses; A[1] = 0; B[1] = 0;
+          st16[1] = sDone * kStUnit; A[1] = 0; B[1] = 0;
         }
         if (row < 0) row = row_base() + cur.first;          // uniform: the first pass of this chunk
         // the cheaper conversion when no row of the wave has a long number or a long code
