@@ -87,8 +87,7 @@ struct acmpc_ctx {
   int fuse = 1;                     // 0: always the four-launch sequence (ACMPC_FUSE=0)
   DevBuf<uint32_t> d_cust_slab;
   // order-restoring path for rows in any order: two sets of (order index, value) records, counters
-  DevBuf<uint32_t> d_part_idx[2];
-  DevBuf<int64_t> d_part_val[2];
+  DevBuf<unsigned long long> d_part_rec[2];   // records of the order-restoring path after its two scatter passes
   DevBuf<unsigned long long> d_part_meta;
   int partition = 1;                // 0: rows in any order always go through the atomic kernel (ACMPC_PARTITION=0)
   DevBuf<unsigned long long> d_cust_carry;
@@ -423,8 +422,8 @@ int launch_lines_any(acmpc_ctx* ctx, const LinesPlan& pl, size_t lds_bytes, cons
 // The order-restoring path (acmpc_partition.hpp): queues count, scan, two scatter passes and the per-bucket
 // reduce.  On return order_total holds every order's total; with !totals_only the stock-delta slabs of
 // `blocks` workgroups are in prod_slab as after k_lines.
-constexpr size_t kPartLdsA = (size_t)2 * kPartCntPitch * 4 + 34 * 8 + (size_t)kPartRound * (8 + 4 + 2);
-constexpr size_t kPartLdsB = (size_t)2 * (kPartMaxBuckets + 4) * 4 + (size_t)kPartMaxBuckets * 8 + (size_t)kPartRoundB * (8 + 4 + 2);
+constexpr size_t kPartLdsA = (size_t)2 * kPartCntPitch * 4 + 34 * 8 + (size_t)kPartRound * (8 + 2);
+constexpr size_t kPartLdsB = (size_t)2 * (kPartMaxBuckets + 4) * 4 + (size_t)kPartMaxBuckets * 8 + (size_t)kPartRoundB * (8 + 2);
 
 bool partition_fits(const acmpc_ctx* ctx, const LinesPlan& lp, int64_t n_orders) {
   return ctx->partition && !ctx->force_global_tables && lp.lds_tables && lp.price_lds && lp.hist_lds && lp.price32 &&
@@ -435,10 +434,8 @@ bool partition_fits(const acmpc_ctx* ctx, const LinesPlan& lp, int64_t n_orders)
 int launch_partition(acmpc_ctx* ctx, PartArgs& a, int blocks, hipStream_t st) {
   int rc;
   const size_t n = (size_t)std::max<int64_t>(a.n_lines, 1);
-  for (int k = 0; k < 2; ++k) {
-    if ((rc = ensure(ctx, ctx->d_part_idx[k], n))) return rc;
-    if ((rc = ensure(ctx, ctx->d_part_val[k], n))) return rc;
-  }
+  for (int k = 0; k < 2; ++k)
+    if ((rc = ensure(ctx, ctx->d_part_rec[k], n))) return rc;
   const size_t n_meta = (size_t)kPartMaxBuckets * 3 + kPartCoarse + 24;
   if ((rc = ensure(ctx, ctx->d_part_meta, n_meta))) return rc;
   a.counts = ctx->d_part_meta.p;
@@ -447,8 +444,8 @@ int launch_partition(acmpc_ctx* ctx, PartArgs& a, int blocks, hipStream_t st) {
   a.cursor_a = a.cursor_b + kPartMaxBuckets;
   a.changes = a.cursor_a + kPartCoarse;
   a.mode = a.changes + 1;
-  a.idx_a = ctx->d_part_idx[0].p; a.val_a = reinterpret_cast<long long*>(ctx->d_part_val[0].p);
-  a.idx_b = ctx->d_part_idx[1].p; a.val_b = reinterpret_cast<long long*>(ctx->d_part_val[1].p);
+  a.rec_a = ctx->d_part_rec[0].p;
+  a.rec_b = ctx->d_part_rec[1].p;
   a.n_buckets = (int32_t)((a.n_orders + kPartBucket - 1) / kPartBucket);
   HIPCHK(ctx, hipMemsetAsync(a.counts, 0, (size_t)kPartMaxBuckets * 8, st));
   HIPCHK(ctx, hipMemsetAsync(a.changes, 0, 8, st));
@@ -928,7 +925,7 @@ ACMPC_API void acmpc_destroy(acmpc_ctx* ctx) {
   release(ctx->s_order_total); release(ctx->s_product_qty); release(ctx->s_customer_total); release(ctx->s_merged);
   release(ctx->s_synth_off); release(ctx->s_synth_cdf);
   release(ctx->d_edge_idx); release(ctx->d_edge_total);
-  release(ctx->d_part_idx[0]); release(ctx->d_part_idx[1]); release(ctx->d_part_val[0]); release(ctx->d_part_val[1]);
+  release(ctx->d_part_rec[0]); release(ctx->d_part_rec[1]);
   release(ctx->d_part_meta);
   release(ctx->d_dict); release(ctx->d_dict_disp); release(ctx->d_codes); release(ctx->d_chunk_rows); release(ctx->d_ing_tables);
   release(ctx->s_text); release(ctx->d_chunk_bytes); release(ctx->s_emit_value);

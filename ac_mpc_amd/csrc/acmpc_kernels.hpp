@@ -78,8 +78,8 @@ struct LinesArgs {
   int32_t no_hist;                    // the stock deltas are left to k_stock (global-table kernels, k_lines_any)
   const int32_t* order_descuento;     // [M] or null (grouped kLife kernels): totals are stored net of it
   int32_t descuento_mode;
-  // k_lines_any: when not null, run only if this word is zero (it is set when the order-restoring path
-  // takes the rows instead, see acmpc_partition.hpp)
+  // k_lines_any: when not null, the word in which the order-restoring path (acmpc_partition.hpp) says what it
+  // did: 0 nothing (this kernel runs in full), 1 everything (this kernel leaves), 2 the stock deltas only
   const unsigned long long* run_if_zero;
 };
 
@@ -624,8 +624,11 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
   const uint32_t P = (uint32_t)a.n_products;
   if (a.only_if_unsorted && !(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStUnsorted))
     return;                                             // uniform: the whole grid leaves
-  if (a.run_if_zero && *a.run_if_zero != 0ull) return;  // uniform
-  const bool hist = !a.totals_only && !a.no_hist;        // no_hist: k_stock does the stock deltas
+  // run_if_zero names the word in which the order-restoring path says what it did: 0 = nothing (the rows are
+  // near enough to grouped for this kernel), 1 = everything, 2 = the stock deltas but not the order totals
+  const unsigned long long elsewhere = a.run_if_zero ? *a.run_if_zero : 0ull;
+  if (elsewhere == 1ull) return;                         // uniform
+  const bool hist = !a.totals_only && !a.no_hist && elsewhere == 0ull;   // no_hist: k_stock does the stock deltas
   const bool price_lds = a.price_in_lds != 0;
   PriceT* s_price = reinterpret_cast<PriceT*>(smem);
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + (price_lds ? (size_t)a.p_pad * sizeof(PriceT) : 0));
@@ -750,11 +753,11 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
 }
 
 // Fallback helpers: act only if the grouped pass raised kStUnsorted.
-// (need_unsorted: only if the grouped pass raised kStUnsorted; run_if_zero: only if that word is zero)
+// (need_unsorted: only if the grouped pass raised kStUnsorted; run_if_zero: not if that word is 1)
 __global__ void __launch_bounds__(256) k_zero_if_unsorted(int64_t* out, int64_t n, const uint32_t* status, int need_unsorted,
                                                           const unsigned long long* run_if_zero) {
   if (need_unsorted && !(__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStUnsorted)) return;
-  if (run_if_zero && *run_if_zero != 0ull) return;
+  if (run_if_zero && *run_if_zero == 1ull) return;      // (the order-restoring path wrote every total)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = 0;
 }
 

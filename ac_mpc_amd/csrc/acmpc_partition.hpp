@@ -9,8 +9,10 @@
 //                     the order id changes from one line to the next
 //   k_part_scan       bucket offsets, cursors of the two scatter passes; decides whether the rows are far
 //                     enough from grouped for this path (else k_lines_any, one atomic per run, is cheaper)
-//   k_part_scatter_a  (order index, price * qty) of every line, written into one of 32 coarse bins
-//                     (64 buckets each); the stock deltas are taken here as well
+//   k_part_scatter_a  every line becomes one 64-bit record, order index (25 bits) above price * qty (39 bits),
+//                     written into one of 32 coarse bins (64 buckets each); the stock deltas are taken here
+//                     as well.  A value outside [0, 2^39) does not fit a record: the pass then hands the
+//                     totals (not the stock deltas, which it has) to the atomic kernel
 //   k_part_scatter_b  every coarse bin split into its buckets
 //   k_part_reduce     one workgroup per bucket: 64-bit adds into a 128 KB LDS table, totals written once
 //
@@ -51,14 +53,15 @@ struct PartArgs {
   unsigned long long* bucket_off;     // [kPartMaxBuckets + 1] first record of every bucket
   unsigned long long* cursor_a;       // [kPartCoarse] next free record of every coarse bin
   unsigned long long* cursor_b;       // [kPartMaxBuckets] next free record of every bucket
-  uint32_t* idx_a; long long* val_a;  // records after pass A   [n_lines]
-  uint32_t* idx_b; long long* val_b;  // records after pass B   [n_lines]
+  unsigned long long* rec_a;          // records after pass A   [n_lines]
+  unsigned long long* rec_b;          // records after pass B   [n_lines]
   int64_t* order_total;               // [n_orders]
   uint32_t* status;
   // How far from grouped the rows are decides which path sums them: k_part_count counts the places where the
   // order id changes from one line to the next (inside every lane's four lines: three of four places), and
   // k_part_scan sets *mode to 1 (this path) when the estimate exceeds 0.4 changes per line, else to 0 (one
-  // 64-bit atomic per run of equal ids, k_lines_any, which costs about 0.05 ms per million runs).
+  // 64-bit atomic per run of equal ids, k_lines_any, which costs about 0.05 ms per million runs).  Pass A sets
+  // it to 2 when it meets a value that does not fit a record: the atomic kernel then redoes the order totals.
   unsigned long long* changes;        // zero on entry of k_part_count
   unsigned long long* mode;
 };
@@ -67,7 +70,14 @@ __device__ __forceinline__ bool part_skip(const PartArgs& a) {
   return a.only_if_unsorted && !(__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStUnsorted);
 }
 // the scatter passes and the reduce: also when the rows are near enough to grouped for the atomic kernel
-__device__ __forceinline__ bool part_skip_moving(const PartArgs& a) { return part_skip(a) || *a.mode == 0ull; }
+__device__ __forceinline__ bool part_skip_moving(const PartArgs& a) { return part_skip(a) || *a.mode != 1ull; }
+// pass A itself may be the one that sets the mode to 2 while some of its workgroups have yet to start
+__device__ __forceinline__ bool part_skip_scatter_a(const PartArgs& a) { return part_skip(a) || *a.mode == 0ull; }
+
+// A record: the order index in the 25 bits above the 39 bits of the line's value.
+constexpr int kPartValBits = 39;
+constexpr unsigned long long kPartValMask = (1ull << kPartValBits) - 1ull;
+static_assert(kPartShift + 11 + kPartValBits == 64, "2048 buckets of 16384 orders: 25 bits of order index");
 
 // Lanes of the wave whose key equals this lane's (every lane takes part): BITS ballots.
 template <int BITS>
@@ -96,6 +106,48 @@ __device__ __forceinline__ uint32_t part_rank(uint32_t* s_cnt, uint32_t key, int
   return base + (uint32_t)__popcll(below);
 }
 
+// The same for K records of every lane at once, looking only at the key bits in which two keys of the wave
+// differ at all (found with one OR-reduction over the wave): a round of pass B holds the buckets of one or two
+// coarse bins, six or seven bits of twelve, and rows that are nearly grouped differ in fewer still.
+__device__ __forceinline__ uint32_t part_wave_or(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+template <int K>
+__device__ __forceinline__ void part_rank_many(uint32_t* s_cnt, const uint32_t (&key)[K], int lane, uint32_t (&pos)[K]) {
+  const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key[0]);
+  uint32_t d = 0;
+#pragma unroll
+  for (int i = 0; i < K; ++i) d |= key[i] ^ k0;
+  unsigned long long m[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) m[i] = ~0ull;
+  for (uint32_t bits = part_wave_or(d); bits; bits &= bits - 1u) {      // uniform
+    const int b = __ffs((int)bits) - 1;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const bool bit = (key[i] >> b) & 1u;
+      const unsigned long long s = __ballot(bit);
+      m[i] &= bit ? s : ~s;
+    }
+  }
+  // records of different slots i that share a bin: slot by slot, so that the counter orders them
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const unsigned long long below = lane == 0 ? 0ull : (m[i] & (~0ull >> (64 - lane)));
+    const int leader = __ffsll((long long)m[i]) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = __hip_atomic_fetch_add(&s_cnt[key[i]], (uint32_t)__popcll(m[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    base = (uint32_t)__shfl((int)base, leader);
+    pos[i] = base + (uint32_t)__popcll(below);
+  }
+}
+
 // ---- lines per bucket ----------------------------------------------------------------------------
 __global__ void __launch_bounds__(kPartThreads) k_part_count(PartArgs a) {
   __shared__ uint32_t s_cnt[kPartMaxBuckets];
@@ -105,8 +157,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_count(PartArgs a) {
   uint32_t st = 0;
   uint32_t changes = 0;
   const long long n4 = a.n_lines / 4;
-  for (long long q = (long long)blockIdx.x * kPartThreads + threadIdx.x; q < n4; q += (long long)gridDim.x * kPartThreads) {
-    const int4 v = load_stream16(a.order_id + 4 * q);
+  auto take4 = [&](const int4& v) {
     const int ids[4] = {v.x, v.y, v.z, v.w};
     changes += (v.x != v.y) + (v.y != v.z) + (v.z != v.w);
 #pragma unroll
@@ -125,6 +176,24 @@ __global__ void __launch_bounds__(kPartThreads) k_part_count(PartArgs a) {
       } else if (ok) {
         __hip_atomic_fetch_add(&s_cnt[bucket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+    }
+  };
+  // four 16-byte loads of a thread in flight
+  const long long stride = (long long)gridDim.x * kPartThreads;
+  const long long q0 = (long long)blockIdx.x * kPartThreads + (threadIdx.x & ~63u);      // the wave's first group
+  const int lane = (int)(threadIdx.x & 63);
+  for (long long qw = q0; qw < n4; qw += 4 * stride) {
+    int4 v[4];
+    bool in[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long long q = qw + (long long)k * stride + lane;
+      in[k] = q < n4;
+      v[k] = in[k] ? load_stream16(a.order_id + 4 * q) : make_int4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (in[k]) take4(v[k]);                               // (the ballots in there count the lanes that are here)
     }
   }
   if (blockIdx.x == 0 && (long long)threadIdx.x < a.n_lines - 4 * n4) {
@@ -169,49 +238,50 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scan(PartArgs a) {
   }
 }
 
-// The binning both scatter passes share.  On entry every thread holds up to four records (bin, idx, val;
-// bin == n_bins: not a record) and has taken its rank inside (wave, bin) from the wave's counters; s_tot
-// holds the records per bin of this round.  Reserves the runs, stages the records bin by bin in LDS and
-// writes the runs out.
+// The binning both scatter passes share, in two steps.  On entry every thread holds up to K records (bin, rec;
+// bin == n_bins: not a record) and has taken its rank inside its bin from the round's counters; s_start holds
+// the first staging slot of every bin.  part_stage_round puts the records bin by bin into LDS; after a barrier
+// part_write_round writes the runs out, to s_gbase[bin] onwards.  The returning atomics that reserve the runs
+// are issued before the staging and their results stored into s_gbase after it, so that they are on their way
+// while the round is staged.
 //   s_start [n_bins + 1]   first staging slot of every bin      s_gbase [n_bins]   first record of its run
 template <int N_BINS, int K>
-__device__ __forceinline__ void part_write_round(const uint32_t (&bin)[K], const uint32_t (&idx)[K], const long long (&val)[K],
-                                                 const uint32_t (&pos)[K], uint32_t* s_start, unsigned long long* s_gbase,
-                                                 uint32_t* s_idx, long long* s_val, unsigned short* s_bin,
-                                                 uint32_t* idx_out, long long* val_out) {
+__device__ __forceinline__ void part_stage_round(const uint32_t (&bin)[K], const unsigned long long (&rec)[K],
+                                                 const uint32_t (&pos)[K], const uint32_t* s_start,
+                                                 unsigned long long* s_rec, unsigned short* s_bin) {
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     if (bin[i] < (uint32_t)N_BINS) {
       const uint32_t p = s_start[bin[i]] + pos[i];
-      s_idx[p] = idx[i];
-      s_val[p] = val[i];
+      s_rec[p] = rec[i];
       s_bin[p] = (unsigned short)bin[i];
     }
   }
-  __syncthreads();
+}
+template <int N_BINS>
+__device__ __forceinline__ void part_write_round(const uint32_t* s_start, const unsigned long long* s_gbase,
+                                                 const unsigned long long* s_rec, const unsigned short* s_bin,
+                                                 unsigned long long* rec_out) {
   const uint32_t total = s_start[N_BINS];
   for (uint32_t e = threadIdx.x; e < total; e += kPartThreads) {
     const uint32_t b = s_bin[e];
-    const unsigned long long g = s_gbase[b] + (e - s_start[b]);
-    idx_out[g] = s_idx[e];
-    val_out[g] = s_val[e];
+    rec_out[s_gbase[b] + (e - s_start[b])] = s_rec[e];
   }
 }
 
 // ---- pass A: lines -> (order index, value) records in 32 coarse bins; stock deltas --------------------
-// LDS: [price int32 p_pad][histogram p_pad][counters 36][start 36][gbase 34 x 8][val 4096 x 8][idx 4096 x 4][bin 4096 x 2]
+// LDS: [price int32 p_pad][histogram p_pad][counters 36][start 36][gbase 34 x 8][records 4096 x 8][bin 4096 x 2]
 __global__ void __launch_bounds__(kPartThreads) k_part_scatter_a(PartArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  if (part_skip_moving(a)) return;
+  if (part_skip_scatter_a(a)) return;
   const int tid = (int)threadIdx.x, lane = tid & 63;
   int32_t* s_price = reinterpret_cast<int32_t*>(smem);
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem) + a.p_pad;
   uint32_t* s_cnt = s_hist + a.p_pad;                                     // [33] (+3): records per bin of this round
   uint32_t* s_start = s_cnt + kPartCntPitch;                              // [33] (+3)
   unsigned long long* s_gbase = reinterpret_cast<unsigned long long*>(s_start + kPartCntPitch);   // [32] (+2)
-  long long* s_val = reinterpret_cast<long long*>(s_gbase + 34);          // [4096]
-  uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_val + kPartRound);      // [4096]
-  unsigned short* s_bin = reinterpret_cast<unsigned short*>(s_idx + kPartRound);      // [4096]
+  unsigned long long* s_rec = s_gbase + 34;                               // [4096]
+  unsigned short* s_bin = reinterpret_cast<unsigned short*>(s_rec + kPartRound);      // [4096]
   const bool hist = !a.totals_only;
   for (int i = tid; i < a.n_products + 1; i += kPartThreads) { s_price[i] = (int32_t)a.price[i]; s_hist[i] = 0u; }
   if (tid < kPartCntPitch) s_cnt[tid] = 0u;
@@ -246,16 +316,19 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_a(PartArgs a) {
     for (int i = 0; i < 4; ++i) { ids[i] = nid[i]; prs[i] = npr[i]; qs[i] = nq[i]; }
     const long long l0 = r * kPartRound + (long long)tid * 4;
     if (r + gridDim.x < n_rounds) load_round(r + gridDim.x, nid, npr, nq);     // in flight while this round is binned
-    uint32_t bin[4], idx[4], pos[4];
-    long long val[4];
+    uint32_t bin[4], pos[4];
+    unsigned long long rec[4];
+    bool wide = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      idx[i] = (uint32_t)ids[i] - (uint32_t)a.base;
-      const bool ok = idx[i] < (uint32_t)a.n_orders;
+      const uint32_t idx = (uint32_t)ids[i] - (uint32_t)a.base;
+      const bool ok = idx < (uint32_t)a.n_orders;
       if (!ok && l0 + i < a.n_lines) st |= kStOrderRange;
-      bin[i] = ok ? (idx[i] >> (kPartShift + kPartCoarseShift)) : (uint32_t)kPartCoarse;
+      bin[i] = ok ? (idx >> (kPartShift + kPartCoarseShift)) : (uint32_t)kPartCoarse;
       const uint32_t pi = min((uint32_t)prs[i], P);
-      val[i] = (long long)s_price[pi] * (long long)qs[i];
+      const unsigned long long val = (unsigned long long)((long long)s_price[pi] * (long long)qs[i]);
+      wide |= ok && val > kPartValMask;
+      rec[i] = ((unsigned long long)idx << kPartValBits) | (val & kPartValMask);
       if (hist) {
         if ((uint32_t)qs[i] < a.q_small)
           __hip_atomic_fetch_add(&s_hist[pi], (uint32_t)qs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -263,22 +336,27 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_a(PartArgs a) {
           atomicAdd(&a.prod_carry[pi], (unsigned long long)(long long)qs[i]);
       }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pos[i] = part_rank<6>(s_cnt, bin[i], lane);
+    part_rank_many<4>(s_cnt, bin, lane, pos);
     __syncthreads();
     // one thread per bin: where the bin starts in the staging area; reserve its run
+    unsigned long long g = 0;
+    uint32_t mine = 0;
     if (tid <= kPartCoarse) {
-      const uint32_t mine = tid < kPartCoarse ? s_cnt[tid] : 0u;          // the drop bin takes no room
+      mine = tid < kPartCoarse ? s_cnt[tid] : 0u;                          // the drop bin takes no room
+      s_cnt[tid] = 0u;                                                     // for the next round (three barriers from here)
+      if (mine) g = atomicAdd(&a.cursor_a[tid], (unsigned long long)mine); // on its way during the staging
       uint32_t incl = mine;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
       s_start[tid] = incl - mine;                                          // s_start[32] == records of this round
-      if (mine) s_gbase[tid] = atomicAdd(&a.cursor_a[tid], (unsigned long long)mine);
     }
     __syncthreads();
-    part_write_round<kPartCoarse, 4>(bin, idx, val, pos, s_start, s_gbase, s_idx, s_val, s_bin, a.idx_a, a.val_a);
-    if (tid < kPartCntPitch) s_cnt[tid] = 0u;          // (nobody reads the counters after the barrier above)
+    if (wide) __hip_atomic_store(a.mode, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the records are not used then)
+    part_stage_round<kPartCoarse, 4>(bin, rec, pos, s_start, s_rec, s_bin);
+    if (mine) s_gbase[tid] = g;
     __syncthreads();
+    // (no barrier here: the next round touches the staging area only after its own three barriers)
+    part_write_round<kPartCoarse>(s_start, s_gbase, s_rec, s_bin, a.rec_a);
   }
   if (st) atomicOr(a.status, st);
   if (hist) {
@@ -291,7 +369,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_a(PartArgs a) {
 // Rounds of 8192 records (two groups of four per thread): the wait for the returning atomics that reserve
 // the runs comes once per round, and a round's records fall into the 64 to 128 buckets of one or two coarse
 // bins, so the longer the round the longer the runs.
-// LDS: [counters 2052][start 2052][gbase 2048 x 8][val 8192 x 8][idx 8192 x 4][bin 8192 x 2]
+// LDS: [counters 2052][start 2052][gbase 2048 x 8][records 8192 x 8][bin 8192 x 2]
 constexpr int kPartRoundB = 2 * kPartRound;
 __global__ void __launch_bounds__(kPartThreads) k_part_scatter_b(PartArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -300,55 +378,53 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_b(PartArgs a) {
   uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem);                    // [2049] (+3): records per bucket of this round
   uint32_t* s_start = s_cnt + kPartMaxBuckets + 4;                        // [2049] (+3)
   unsigned long long* s_gbase = reinterpret_cast<unsigned long long*>(s_start + kPartMaxBuckets + 4);   // [2048]
-  long long* s_val = reinterpret_cast<long long*>(s_gbase + kPartMaxBuckets);
-  uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_val + kPartRoundB);
-  unsigned short* s_bin = reinterpret_cast<unsigned short*>(s_idx + kPartRoundB);
+  unsigned long long* s_rec = s_gbase + kPartMaxBuckets;
+  unsigned short* s_bin = reinterpret_cast<unsigned short*>(s_rec + kPartRoundB);
   __shared__ uint32_t s_w[kPartWaves];
   for (int i = tid; i < kPartMaxBuckets + 4; i += kPartThreads) s_cnt[i] = 0u;
   __syncthreads();
   const long long n_rec = (long long)a.bucket_off[kPartMaxBuckets];
   const long long n_rounds = (n_rec + kPartRoundB - 1) / kPartRoundB;
 
-  // thread t holds records 4t .. 4t+3 of each half of the round
-  auto load_round = [&](long long r, uint32_t (&idx)[8], long long (&val)[8]) {
+  // thread t holds records 4t .. 4t+3 of each half of the round (two 16-byte loads per half)
+  auto load_round = [&](long long r, unsigned long long (&rec)[8]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const long long e0 = r * kPartRoundB + (long long)h * kPartRound + (long long)tid * 4;
       if (e0 + 4 <= n_rec) {
-        const int4 v = load_stream16(reinterpret_cast<const int32_t*>(a.idx_a + e0));
-        idx[4 * h] = (uint32_t)v.x; idx[4 * h + 1] = (uint32_t)v.y; idx[4 * h + 2] = (uint32_t)v.z; idx[4 * h + 3] = (uint32_t)v.w;
         long long q[4];
-        load_prices<4>(a.val_a + e0, q);
+        load_prices<4>(reinterpret_cast<const long long*>(a.rec_a + e0), q);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) val[4 * h + i] = q[i];
+        for (int i = 0; i < 4; ++i) rec[4 * h + i] = (unsigned long long)q[i];
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool in = e0 + i < n_rec;
-          idx[4 * h + i] = in ? a.idx_a[e0 + i] : 0xffffffffu;        // past the end: no bucket
-          val[4 * h + i] = in ? a.val_a[e0 + i] : 0ll;
-        }
+        for (int i = 0; i < 4; ++i) rec[4 * h + i] = e0 + i < n_rec ? a.rec_a[e0 + i] : 0ull;    // (past the end: dropped below)
       }
     }
   };
 
   long long r = blockIdx.x;
-  uint32_t nidx[8];
-  long long nval[8];
-  if (r < n_rounds) load_round(r, nidx, nval);
+  unsigned long long nrec[8];
+  if (r < n_rounds) load_round(r, nrec);
   for (; r < n_rounds; r += gridDim.x) {
-    uint32_t bin[8], idx[8], pos[8];
-    long long val[8];
+    uint32_t bin[8], pos[8];
+    unsigned long long rec[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { idx[i] = nidx[i]; val[i] = nval[i]; }
-    if (r + gridDim.x < n_rounds) load_round(r + gridDim.x, nidx, nval);
+    for (int i = 0; i < 8; ++i) rec[i] = nrec[i];
+    if (r + gridDim.x < n_rounds) load_round(r + gridDim.x, nrec);
+    // every bucket number is a record's; places past the last record go to the drop bin
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bin[i] = min(idx[i] >> kPartShift, (uint32_t)kPartMaxBuckets);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) pos[i] = part_rank<12>(s_cnt, bin[i], lane);
+    for (int i = 0; i < 8; ++i) {
+      const long long e = r * kPartRoundB + (long long)(i >> 2) * kPartRound + (long long)tid * 4 + (i & 3);
+      bin[i] = e < n_rec ? (uint32_t)(rec[i] >> (kPartValBits + kPartShift)) : (uint32_t)kPartMaxBuckets;
+    }
+    part_rank_many<8>(s_cnt, bin, lane, pos);
     __syncthreads();
     // one thread per pair of buckets: where they start in the staging area; reserve their runs
     const uint32_t t0 = s_cnt[2 * tid], t1 = s_cnt[2 * tid + 1];
+    s_cnt[2 * tid] = 0u;                               // for the next round (three barriers from here)
+    s_cnt[2 * tid + 1] = 0u;
+    if (tid == 0) s_cnt[kPartMaxBuckets] = 0u;
     unsigned long long g0 = 0, g1 = 0;
     if (t0) g0 = atomicAdd(&a.cursor_b[2 * tid], (unsigned long long)t0);       // in flight during the scan
     if (t1) g1 = atomicAdd(&a.cursor_b[2 * tid + 1], (unsigned long long)t1);
@@ -362,14 +438,13 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_b(PartArgs a) {
     s_start[2 * tid] = off;
     s_start[2 * tid + 1] = off + t0;
     if (tid == kPartThreads - 1) s_start[kPartMaxBuckets] = off + t0 + t1;
-    if (t0) s_gbase[2 * tid] = g0;
+    __syncthreads();
+    part_stage_round<kPartMaxBuckets, 8>(bin, rec, pos, s_start, s_rec, s_bin);
+    if (t0) s_gbase[2 * tid] = g0;                     // (the atomics have been on their way since before the scan)
     if (t1) s_gbase[2 * tid + 1] = g1;
     __syncthreads();
-    part_write_round<kPartMaxBuckets, 8>(bin, idx, val, pos, s_start, s_gbase, s_idx, s_val, s_bin, a.idx_b, a.val_b);
-    s_cnt[2 * tid] = 0u;                               // (nobody reads the counters after the barrier above)
-    s_cnt[2 * tid + 1] = 0u;
-    if (tid == 0) s_cnt[kPartMaxBuckets] = 0u;
-    __syncthreads();
+    // (no barrier here: the next round touches the staging area only after its own three barriers)
+    part_write_round<kPartMaxBuckets>(s_start, s_gbase, s_rec, s_bin, a.rec_b);
   }
 }
 
@@ -383,22 +458,21 @@ __global__ void __launch_bounds__(kPartThreads) k_part_reduce(PartArgs a) {
   for (int i = tid * 2; i < kPartBucket; i += kPartThreads * 2) *reinterpret_cast<uint4*>(s_tab + i) = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   const long long lo = (long long)a.bucket_off[b], hi = (long long)a.bucket_off[b + 1];
-  // four records a thread in flight (a bucket starts anywhere, so single 4- and 8-byte loads; consecutive
-  // lanes read consecutive records)
-  for (long long e = lo + tid; e < hi; e += 4 * kPartThreads) {
-    uint32_t idx[4];
-    long long v[4];
+  // eight records a thread in flight (a bucket starts anywhere, so single 8-byte loads; consecutive lanes
+  // read consecutive records)
+  constexpr int kDepth = 8;
+  for (long long e = lo + tid; e < hi; e += kDepth * kPartThreads) {
+    unsigned long long rec[kDepth];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kDepth; ++k) {
       const long long ek = e + (long long)k * kPartThreads;
-      const bool in = ek < hi;
-      idx[k] = in ? a.idx_b[ek] : 0u;
-      v[k] = in ? a.val_b[ek] : 0ll;
+      rec[k] = ek < hi ? a.rec_b[ek] : 0ull;
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < kDepth; ++k)
       if (e + (long long)k * kPartThreads < hi)
-        __hip_atomic_fetch_add(&s_tab[idx[k] & (kPartBucket - 1)], (unsigned long long)v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&s_tab[(rec[k] >> kPartValBits) & (kPartBucket - 1)], rec[k] & kPartValMask, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __syncthreads();
   const long long o0 = (long long)b * kPartBucket;

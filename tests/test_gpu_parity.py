@@ -458,6 +458,28 @@ def test_any_line_order_rough_values(motor, oracle):
                      int(v["order_id_base"]), int(v["n_customers"]), v["price_cents"])
 
 
+@pytest.mark.parametrize("what", ["one_wide", "negative_qty", "all_wide"])
+def test_any_line_order_values_that_do_not_fit_a_record(motor, oracle, what):
+    """The order-restoring path carries a line's value in 39 bits; one line whose price * qty is 2^39 or more, or
+    negative (a return), sends the order totals through the atomic kernel while the stock deltas stay with the
+    partition pass.  Both modes, shuffled rows."""
+    n, p, c = 2_000_003, 2_000, 30_000
+    d = oracle.synth(n, p, c, zipf=1, qty_mode=1)
+    oid, pidx, qty = d["order_id"].copy(), d["product_idx"].copy(), d["qty"].copy()
+    price = oracle.synth_prices(p).copy()
+    if what == "one_wide":
+        price[7] = 2_000_000_000
+        k = int(np.flatnonzero(pidx == 7)[0])
+        qty[k] = 1_000                                    # 2e12 > 2^39
+    elif what == "negative_qty":
+        qty[1_234_567] = -3
+    else:
+        price[:] = 2_100_000_000
+        qty[:] = 1_000_000 + (qty % 7)                   # every value about 2e15
+    perm = np.random.default_rng(37).permutation(n)
+    _check_any_order(motor, oracle, oid[perm], pidx[perm], qty[perm], d["order_customer"], 5, c, price)
+
+
 def test_grouped_mode_still_rejects_shuffled_rows(motor, oracle):
     d = oracle.synth(50_000, 100, 50)
     perm = np.random.default_rng(31).permutation(50_000)
