@@ -1406,7 +1406,8 @@ ACMPC_API int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, in
   HIPCHK(ctx, hipMemsetAsync(ctx->d_chunk_rows.p, 0, ((size_t)a.n_chunks + kTicketWords64) * 8, st));
   const int blocks = (int)std::min<int64_t>(a.n_chunks, (int64_t)ctx->n_cu * kIngBlocksPerCu);
   a.n_stripes = std::min(blocks, kIngStripes);
-  hipLaunchKernelGGL(k_ingest_parse, dim3(blocks), dim3(kIngThreads), 0, st, a);
+  if (a.ablate) hipLaunchKernelGGL(k_ingest_parse<true>, dim3(blocks), dim3(kIngThreads), 0, st, a);
+  else hipLaunchKernelGGL(k_ingest_parse<false>, dim3(blocks), dim3(kIngThreads), 0, st, a);
   HIPCHK(ctx, hipGetLastError());
   return ACMPC_OK;
 }

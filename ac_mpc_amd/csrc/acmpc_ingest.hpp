@@ -446,7 +446,7 @@ __device__ __forceinline__ void ing_scan_rows(const unsigned char* s_text, const
 // Returns false when the row is malformed.  W1, W2: words of digits read for the two numbers; NC: words
 // of the code that are cut out (the rest are zero).  The caller picks <3, 3, 8>, which covers every row,
 // or a cheaper combination when no row of the wave needs more.
-template <int W1, int W2, int NC>
+template <int W1, int W2, int NC, bool kDev = false>
 __device__ __forceinline__ bool ing_finish_row(const unsigned char* s_text, int p, uint32_t st16, uint32_t A, uint32_t B,
                                                const IngestArgs& a, int32_t& oid, int32_t& pidx, int32_t& qty) {
   const int nd1 = (A >> kANd1) & 127, nd2 = (A >> kANd2) & 127, cl = (A >> kACl) & 127, len = (A >> kALen) & 127;
@@ -473,7 +473,7 @@ __device__ __forceinline__ bool ing_finish_row(const unsigned char* s_text, int 
     lo = hi;
   }
   pidx = -1;
-  if (ok && !(a.ablate & 2)) {
+  if (ok && !(kDev && (a.ablate & 2))) {
     // dictionary lookup: bucket displacement (a small, cache-resident table), then the one slot this code
     // can live in; the slot holds the code itself, so equality is decided without another round trip
     const IngHash h = ing_code_hash(cw, a.dict_seed);
@@ -557,7 +557,10 @@ constexpr int kIngBuf = kIngFront + kIngChunk + kIngLook + 64;
 // in the other text buffer — parsed and written, because its first output row is the sum of the counts
 // of all chunks before it, and looking back over them is cheapest when it is done late.  The text of chunk
 // i + 2 is requested before the parse and waits in registers; so does the ticket after it.
+// kDev: the developer switches of IngestArgs::ablate are compiled in (timing experiments only).
+template <bool kDev>
 __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_eu(kIngBlocksPerCu * kIngThreads / 256, kIngBlocksPerCu * kIngThreads / 256))) k_ingest_parse(IngestArgs a) {
+  const int ablate = kDev ? a.ablate : 0;
   // [16 bytes of slack][chunk][look-ahead][slack]: number and code windows may reach a few bytes outside a row
   __shared__ __align__(16) unsigned char s_text[2][kIngBuf];
   __shared__ __align__(8) uint2 s_T[kIngTableWords];
@@ -582,9 +585,16 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
   uint32_t rprev = (uint32_t)'\n';
   auto request_text = [&](int64_t c) {
     const int64_t cbase = c * kIngChunk;
+    if (cbase + kIngChunk + kIngLook <= a.n_bytes) {       // uniform: every chunk but the last one or two
+      const uint4* src = reinterpret_cast<const uint4*>(a.text + cbase + o);
 #pragma unroll
-    for (int j = 0; j < kIngPerThread / 16; ++j) rt[j] = ing_load_piece(a.text, cbase + o + 16 * j, a.n_bytes);
-    if (tid < kIngLook / 16) rl = ing_load_piece(a.text, cbase + kIngChunk + 16 * tid, a.n_bytes);
+      for (int j = 0; j < kIngPerThread / 16; ++j) rt[j] = src[j];
+      if (tid < kIngLook / 16) rl = *reinterpret_cast<const uint4*>(a.text + cbase + kIngChunk + 16 * tid);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kIngPerThread / 16; ++j) rt[j] = ing_load_piece(a.text, cbase + o + 16 * j, a.n_bytes);
+      if (tid < kIngLook / 16) rl = ing_load_piece(a.text, cbase + kIngChunk + 16 * tid, a.n_bytes);
+    }
     if (tid == 0) rprev = c > 0 ? (uint32_t)a.text[cbase - 1] : (uint32_t)'\n';
   };
   // Chunks are handed out in text order within a stripe: stripe s = blockIdx % n_stripes owns the chunks
@@ -638,7 +648,7 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
       for (unsigned long long m = smask; m; m &= m - 1ull) {
         const int k = __ffsll((long long)m) - 1;
         const uint32_t c0 = t[o + k];
-        const uint32_t c1 = k + 1 < left ? (uint32_t)t[o + k + 1] : 0u;
+        const uint32_t c1 = t[o + k + 1];                    // (past the end of the text: the sentinel or 0, no digit)
         if (ing_data_row(c0, c1)) nxt.rows |= 1ull << k;
         else if ((c0 | 0x20u) == 'i') {
           // (bytes past the end of the text: the sentinel newline stops the search; a statement line takes
@@ -665,7 +675,7 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
       for (int k = 0; k < kIngThreads / 64; ++k) { if (k < wave) woff += s_w[k]; n_next += s_w[k]; }
       nxt.first += woff;
       // publish as early as possible: successors add this count up long before this chunk knows its base
-      if (tid == 0 && !(a.ablate & 64)) ing_publish_own(a.chunk_state, c_next, n_next);
+      if (tid == 0 && !(ablate & 64)) ing_publish_own(a.chunk_state, c_next, n_next);
       c_after = s_tk[par];
       if (c_after < a.n_chunks) {
         request_text(c_after);
@@ -680,11 +690,11 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
       // the memory side nothing).  The first round of its loads is issued here and used after the first rows
       // have been through the automaton, which needs no row base.
       unsigned long long look = kIngInclusive;
-      if (wave == 0 && !(a.ablate & 64)) look = ing_look_first(a.chunk_state, c_cur, lane);
+      if (wave == 0 && !(ablate & 64)) look = ing_look_first(a.chunk_state, c_cur, lane);
       auto row_base = [&]() -> long long {
         long long rbase;
         if (wave == 0) {
-          rbase = (a.ablate & 64) ? c_cur * 400 : ing_row_base(a.chunk_state, c_cur, n_cur, lane, a.status, look);
+          rbase = (ablate & 64) ? c_cur * 400 : ing_row_base(a.chunk_state, c_cur, n_cur, lane, a.status, look);
           if (lane == 0) {
             s_base[par] = rbase;
             __hip_atomic_store(&s_base_of[par], c_cur + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -716,12 +726,12 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
         if (!have) return;
         int32_t oid = 0, pidx = -1, qty = 0;
         bool ok = true;
-        if (!(a.ablate & 1)) {
-          if (!wide) ok = ing_finish_row<2, 1, 3>(tx, p, st16, A, B, a, oid, pidx, qty);
-          else ok = ing_finish_row<3, 3, 8>(tx, p, st16, A, B, a, oid, pidx, qty);
+        if (!(ablate & 1)) {
+          if (!wide) ok = ing_finish_row<2, 1, 3, kDev>(tx, p, st16, A, B, a, oid, pidx, qty);
+          else ok = ing_finish_row<3, 3, 8, kDev>(tx, p, st16, A, B, a, oid, pidx, qty);
         }
         if (!ok) { ++bad; oid = 0; pidx = -1; qty = 0; }
-        if (row < a.capacity && !(a.ablate & 8)) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }
+        if (row < a.capacity && !(ablate & 8)) { a.order_id[row] = oid; a.product_idx[row] = pidx; a.qty[row] = qty; }
         ++row;
       };
       auto plain = [](uint32_t A) {
@@ -736,7 +746,7 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
         p[1] = take(have[1]);
         uint32_t st16[2], A[2], B[2];
         const bool two = __ballot(have[1]) != 0ull;
-        if (a.ablate & 4) { st16[0] = st16[1] = sDone * kStUnit; A[0] = A[1] = 0x01000000u; B[0] = B[1] = 0; }
+        if (ablate & 4) { st16[0] = st16[1] = sDone * kStUnit; A[0] = A[1] = 0x01000000u; B[0] = B[1] = 0; }
         else if (two) ing_scan_rows<2>(tx, s_ct, s_T, p, have, st16, A, B);
         else {
           const int p1[1] = {p[0]};
