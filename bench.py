@@ -299,6 +299,7 @@ def main():
     # (tools/profile_gpu.sh) and kept in profiles/pmc_traffic.json with a digest of the sources they were
     # collected with; a record of other kernels than the ones that ran just now is not quoted.
     traffic, traffic_note = None, "no PMC record for this workload"
+    step_traffic = None                     # HBM bytes of all kernels of one step, same counters
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -306,6 +307,7 @@ def main():
             if rec:
                 if rec.get("source_digest") == kernel_source_digest():
                     traffic, traffic_note = rec.get("hbm_bytes_per_launch"), rec.get("source", "")
+                    step_traffic = rec.get("step_hbm_bytes")
                 else:
                     traffic_note = (f"PMC record is of sources {rec.get('source_digest')}, these are "
                                     f"{kernel_source_digest()}: not quoted")
@@ -355,6 +357,11 @@ def main():
                 "whole_step_algorithmic_GBs": b_step / (elapsed / args.steps) / 1e9,
                 "whole_step_frac": b_step / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS,
                 "whole_step_device_ms": step_ms_device,
+                # HBM bytes all kernels of a step really move (FETCH_SIZE / WRITE_SIZE counters, same record and
+                # correction as `traffic`), over the same wall time: how busy the memory is, re-reads included
+                "whole_step_hbm_bytes_counters": step_traffic,
+                "whole_step_hbm_frac_counters": (step_traffic / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS
+                                                 if step_traffic and world == 1 else None),
                 # measured in this run: a plain device-to-device copy (read + written bytes per second)
                 "device_copy_GBs": copy_gbs,
                 "frac_of_device_copy": achieved / copy_gbs if copy_gbs else None,

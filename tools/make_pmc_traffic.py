@@ -42,7 +42,12 @@ def main():
             continue
         k = lines[0]
         f_kb, w_kb = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
+        # every kernel of one step (the generator is not part of it), same correction
+        step = {kk: 2 * fetch[kk]["FETCH_SIZE"] * 1024 + (write.get(kk, {}).get("WRITE_SIZE") or 0.0) * 1024
+                for kk in fetch if "k_synth" not in kk}
         rec[name] = {
+            "step_hbm_bytes": sum(step.values()),
+            "step_hbm_bytes_by_kernel": {kk.split("acmpc::")[-1]: v for kk, v in step.items()},
             "hbm_bytes_per_launch": 2 * f_kb * 1024 + w_kb * 1024,
             "fetch_bytes_corrected": 2 * f_kb * 1024,
             "write_bytes": w_kb * 1024,
