@@ -406,6 +406,39 @@ def test_one_shard_of_the_1g_line_configurations(motor, oracle, zipf, rank):
         assert int(epq[0]) > 10 * int(epq[p // 2])           # the hot product really is hot in this shard
 
 
+def test_first_call_of_a_context_on_a_side_stream(oracle):
+    """The call that allocates (and zeroes) the workspace runs on a stream of its own, which does not order
+    against the null stream: the zeroing has to be queued on the call's stream too.  Grouped and any-order rows."""
+    import torch
+    from ac_mpc_amd import MotorLote
+    m = MotorLote(0)
+    try:
+        n, p, c = 3_000_001, 2_000, 30_000
+        ds = sintetico.generar(m, n, p, c, zipf=True, qty_mode=1)
+        d = oracle.synth(n, p, c, zipf=1, qty_mode=1)
+        etot, epq, ect, flags = oracle.aggregate(d["order_id"], d["product_idx"], d["qty"], d["order_customer"],
+                                                 d["order_id_base"], c, ds.price_cents)
+        assert flags == 0
+        dev = ds.order_id.device
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=dev)
+        for modo in (False, True):
+            m.orden_lineas(modo)
+            tot = torch.empty(ds.n_orders, dtype=torch.int64, device=dev)
+            pq = torch.empty(p, dtype=torch.int64, device=dev)
+            ct = torch.empty(c, dtype=torch.int64, device=dev)
+            with torch.cuda.stream(side):
+                m.agregar_device(ds.order_id, ds.product_idx, ds.qty, ds.order_customer, ds.order_id_base, c, tot, pq, ct,
+                                 stream=side.cuda_stream)
+            assert m.estado(side.cuda_stream) == 0
+            np.testing.assert_array_equal(tot.cpu().numpy(), etot)
+            np.testing.assert_array_equal(pq.cpu().numpy(), epq)
+            np.testing.assert_array_equal(ct.cpu().numpy(), ect)
+    finally:
+        m.orden_lineas(False)
+        m.cerrar()
+
+
 # ---- rows not grouped by order (concurrent checkouts interleave their detalle inserts) ------------
 
 def _check_any_order(motor, oracle, oid, pidx, qty, cust, base, c_n, price):
