@@ -86,3 +86,41 @@ def test_limits_are_refused_with_a_message(oracle):
         assert rc == _lib.E_INVALID and b"grouped path" in m._lib.acmpc_last_error(m._ctx)
     finally:
         m.cerrar()
+
+
+def test_captured_in_a_graph_and_replayed(oracle):
+    """What the entry point is for: a caller under HIP graph capture, where nothing may be allocated.  The
+    replayed graph writes the same three outputs as the call issued directly, also after the inputs changed."""
+    import torch
+    from ac_mpc_amd import MotorLote, sintetico
+    m = MotorLote(0)
+    try:
+        p, c, n = 10_000, 100_000, 2_000_003
+        ds = sintetico.generar(m, n, p, c, zipf=True, qty_mode=1)
+        dev = ds.order_id.device
+        tot = torch.zeros(ds.n_orders, dtype=torch.int64, device=dev)
+        pq = torch.zeros(p, dtype=torch.int64, device=dev)
+        ct = torch.zeros(c, dtype=torch.int64, device=dev)
+        m.agregar_device(ds.order_id, ds.product_idx, ds.qty, ds.order_customer, ds.order_id_base, c, tot, pq, ct,
+                         sin_reservas=True)                 # (first call outside the capture: the library is warm)
+        assert m.estado() == 0
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=torch.cuda.Stream(device=dev)):
+            m.agregar_device(ds.order_id, ds.product_idx, ds.qty, ds.order_customer, ds.order_id_base, c, tot, pq, ct,
+                             stream=torch.cuda.current_stream(dev).cuda_stream, sin_reservas=True)
+        for qty_shift in (0, 1):
+            if qty_shift:
+                ds.qty.add_(1)                              # same buffers, new contents
+            tot.fill_(-7); pq.fill_(-7); ct.fill_(-7)
+            g.replay()
+            torch.cuda.synchronize()
+            assert m.estado() == 0
+            etot, epq, ect, flags = oracle.aggregate(ds.order_id.cpu().numpy(), ds.product_idx.cpu().numpy(),
+                                                     ds.qty.cpu().numpy(), ds.order_customer.cpu().numpy(),
+                                                     ds.order_id_base, c, ds.price_cents)
+            assert flags == 0
+            assert np.array_equal(tot.cpu().numpy(), etot) and np.array_equal(pq.cpu().numpy(), epq)
+            assert np.array_equal(ct.cpu().numpy(), ect)
+    finally:
+        m.cerrar()
