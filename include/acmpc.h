@@ -243,12 +243,14 @@ int acmpc_status(acmpc_ctx* ctx, void* hip_stream, uint32_t* flags);
  *                                  checkouts do not overlap; a violation is reported, not summed
  *   ACMPC_ORDER_ANY                no promise: concurrent checkouts interleave their rows
  *                                  (process/confirmcompra.php:27,35-37; `detalle` has no primary key,
- *                                  store.sql:192-194).  Same results, through 64-bit global atomics
- *                                  per run of equal ids: several times slower.
+ *                                  store.sql:192-194).  Same results.  The device decides how: rows far
+ *                                  from grouped are moved next to their order's neighbourhood (a two-level
+ *                                  partition by order id) and summed there, rows near it are summed with one
+ *                                  64-bit global atomic per run of equal ids.  2.4 to 4 times the grouped time.
  *   ACMPC_ORDER_AUTO               the grouped pass runs first; only if it meets a descending order id
  *                                  are the order totals redone by the any-order pass (decided on the
- *                                  device, without a host round trip).  Costs three near-empty kernel
- *                                  launches when the rows were grouped after all.  An input that is
+ *                                  device, without a host round trip).  Costs a few near-empty kernel
+ *                                  launches (8 % of a step) when the rows were grouped after all.  An input that is
  *                                  not non-decreasing contains a descent, so none slips through.
  * No counterpart in the reference, which never reads `detalle` back.
  */
