@@ -1,6 +1,6 @@
-"""Turn the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_r02.sh into profiles/pmc_traffic.json.
+"""Turn the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh into profiles/pmc_traffic.json.
 
-    python tools/make_pmc_traffic.py gpurun_out/prof_r02 r02
+    python tools/make_pmc_traffic.py gpurun_out/prof_TAG TAG
 
 One entry per workload "lines=<n>,zipf=<z>" for the dominant kernel (k_lines): HBM bytes per launch =
 2 x FETCH_SIZE (gfx950 reports half the bytes of 16-byte-per-lane streaming reads) + WRITE_SIZE, both in

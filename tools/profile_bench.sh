@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-2 profiles on the GPU box (run through gpurun from the repo root):
+# Profiles of the benchmark on the GPU box (run through gpurun from the repo root):
 #   1. rocprofv3 --kernel-trace --stats of bench.py: the default workload, the Zipf workload, and shard 7 of 8 of
 #      the 1 G-line Zipf set (the per-GPU shape of the 8-GPU configurations)
 #   2. separate --pmc FETCH_SIZE / WRITE_SIZE passes over the short C++ tool, uniform and Zipf
 # Outputs land under gpurun_out/prof_$TAG; tools/make_pmc_traffic.py and a few cp's bring the summaries to profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-x}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
