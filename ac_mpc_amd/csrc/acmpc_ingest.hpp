@@ -111,28 +111,6 @@ __device__ __forceinline__ int ing_statement_row(const unsigned char* text, int 
   return -1;
 }
 
-// Bit 7 of every byte of w that equals '\n'.
-__device__ __forceinline__ uint32_t ing_newlines(uint32_t w) {
-  const uint32_t x = w ^ 0x0A0A0A0Au;
-  return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;    // exact per byte: no borrow between bytes
-}
-
-// Bit k set: a line starts at byte k of the thread's 64 bytes (byte k-1 is '\n', or the text starts
-// there).  Lines are not classified here.
-__device__ __forceinline__ unsigned long long ing_line_start_mask(const uint32_t (&w)[kIngWords], uint32_t prev) {
-  unsigned long long mask = 0;
-  uint32_t carry = prev == '\n' ? 0x80u : 0u;
-#pragma unroll
-  for (int j = 0; j < kIngWords; ++j) {
-    const uint32_t nl = ing_newlines(w[j]);
-    const uint32_t st = (nl << 8) | carry;
-    carry = nl >> 24;
-    const uint32_t nib = ((st >> 7) & 1u) | ((st >> 14) & 2u) | ((st >> 21) & 4u) | ((st >> 28) & 8u);
-    mask |= (unsigned long long)nib << (4 * j);
-  }
-  return mask;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Row base of a chunk without a counting pass: chunks are taken in order from a ticket counter, every
 // chunk publishes its row count as soon as it knows it, and looks back over its predecessors' entries

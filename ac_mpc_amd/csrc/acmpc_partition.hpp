@@ -79,36 +79,13 @@ constexpr int kPartValBits = 39;
 constexpr unsigned long long kPartValMask = (1ull << kPartValBits) - 1ull;
 static_assert(kPartShift + 11 + kPartValBits == 64, "2048 buckets of 16384 orders: 25 bits of order index");
 
-// Lanes of the wave whose key equals this lane's (every lane takes part): BITS ballots.
-template <int BITS>
-__device__ __forceinline__ unsigned long long part_peers(uint32_t key) {
-  unsigned long long m = ~0ull;
-#pragma unroll
-  for (int b = 0; b < BITS; ++b) {
-    const bool bit = (key >> b) & 1u;
-    const unsigned long long s = __ballot(bit);
-    m &= bit ? s : ~s;
-  }
-  return m;
-}
-
-// Position of this lane's record among the records of its bin in this round: the lanes of a wave that share
-// a bin take one returning add on the bin's counter between them (made by the lowest of them), so adds to
-// one LDS word from inside a wave never collide, however the keys are distributed.
-template <int BITS>
-__device__ __forceinline__ uint32_t part_rank(uint32_t* s_cnt, uint32_t key, int lane) {
-  const unsigned long long m = part_peers<BITS>(key);
-  const unsigned long long below = lane == 0 ? 0ull : (m & (~0ull >> (64 - lane)));
-  const int leader = __ffsll((long long)m) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = __hip_atomic_fetch_add(&s_cnt[key], (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  base = (uint32_t)__shfl((int)base, leader);
-  return base + (uint32_t)__popcll(below);
-}
-
-// The same for K records of every lane at once, looking only at the key bits in which two keys of the wave
-// differ at all (found with one OR-reduction over the wave): a round of pass B holds the buckets of one or two
-// coarse bins, six or seven bits of twelve, and rows that are nearly grouped differ in fewer still.
+// Position of a lane's records among the records of their bins in this round.  The lanes of a wave that share
+// a bin take one returning add on the bin's counter between them (made by the lowest of them), so adds to one
+// LDS word from inside a wave never collide, however the keys are distributed.  The lanes whose key equals
+// this lane's are found with one ballot per key bit — only the bits in which two keys of the wave differ at
+// all (one OR-reduction over the wave finds those): a round of pass B holds the buckets of one or two coarse
+// bins, six or seven bits of twelve, and rows that are nearly grouped differ in fewer still.  K records of
+// every lane are ranked at once.
 __device__ __forceinline__ uint32_t part_wave_or(uint32_t v) {
   v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
   v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
