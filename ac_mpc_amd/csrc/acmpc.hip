@@ -319,7 +319,10 @@ struct CustPlan {
   int c_pad;
 };
 
-void plan_customers(const acmpc_ctx* ctx, int64_t n_orders, int32_t n_customers, CustPlan* p) {
+// leave_slots: workgroup slots per XCD label that are left to other workgroups of the same launch (the record
+// and merge blocks that ride along with the customer pass): a launch that does not fit the CUs in one go runs
+// its last workgroups after the first have finished, which nearly doubles its time.
+void plan_customers(const acmpc_ctx* ctx, int64_t n_orders, int32_t n_customers, CustPlan* p, int leave_slots = 0) {
   p->threads = ctx->k2_threads;
   const int cus = ctx->k2_cus > 0 ? std::min(ctx->k2_cus, ctx->n_cu) : ctx->n_cu;
   const int slots = std::max(1, cus / 8);                   // workgroups per XCD label, one per CU
@@ -343,7 +346,7 @@ void plan_customers(const acmpc_ctx* ctx, int64_t n_orders, int32_t n_customers,
     p->span = (n_customers + r - 1) / r;
     p->span = (p->span + 3) & ~3;
     p->lds_bytes = (size_t)p->span * 4 + kWave * 4;      // partial sums + one scratch word per lane
-    const int max_groups = std::max(1, slots / r);
+    const int max_groups = std::max(1, (slots - leave_slots) / r);
     // small inputs: fewer streams, so that every stream still has a few tiles per wave
     const int64_t want = std::max<int64_t>(1, (p->n_tiles + 8 * 32 - 1) / (8 * 32));
     const int groups = (int)std::min<int64_t>(max_groups, want);
@@ -562,6 +565,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
   const bool fused = ctx->fuse && ctx->line_order == ACMPC_ORDER_GROUPED && !life && n_lines > 0 &&
                      (n_orders >= 4000000 || (ctx->fuse == 2 && n_orders > 0)) &&
                      lp.lds_tables && lp.hist_lds && cp.lds_tables && cp.threads == kFixThreads;
+  if (fused && cp.blocks + 8 > ctx->n_cu) plan_customers(ctx, n_orders, n_customers, &cp, 1);   // room for the leading blocks
   FixArgs f;
   memset(&f, 0, sizeof(f));
   const size_t fix_lds = (size_t)kFixThreads * kFixStrip * 12;
