@@ -112,6 +112,15 @@ def test_large_product_and_customer_tables_use_global_path(motor, oracle):
     _check(motor, oracle, d["order_id"], d["product_idx"], d["qty"], d["order_customer"], 5, c, oracle.synth_prices(p))
 
 
+@pytest.mark.parametrize("c", [30_000, 39_000, 60_000, 78_001, 150_000, 131_073, 260_000])
+def test_number_of_customer_ranges(motor, oracle, c):
+    """One to seven customer ranges per stream (a workgroup's LDS holds about 39 k partial sums), under both
+    launch sequences: with the record block riding along, the plan leaves room for it on every XCD."""
+    n, p = 1_500_003, 3_000
+    d = oracle.synth(n, p, c, zipf=1, qty_mode=1)
+    _check(motor, oracle, d["order_id"], d["product_idx"], d["qty"], d["order_customer"], 5, c, oracle.synth_prices(p))
+
+
 # ---- edge cases of the data contract -----------------------------------------------------------
 
 def test_empty_input(motor, oracle):
