@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 using namespace acmpc;
@@ -1747,17 +1748,33 @@ ACMPC_API int acmpc_aggregate_sharded(acmpc_ctx* const* ctxs, acmpc_comm* const*
                                                  [](int32_t a, int64_t b) { return (int64_t)a < b; }) - order_id;
   }
   l_cut[0] = 0;                                        // ids below the base stay with shard 0, which reports them
-  int rc;
-  for (int g = 0; g < n_devices; ++g) {
+  // One host thread per device for the two phases that move host memory: a copy from or to pageable memory
+  // holds its calling thread until the data has gone through the staging buffers, so issued from one thread the
+  // shards would cross their PCIe links one after the other.  (A thread sets its own current device.)
+  std::vector<int> rcs((size_t)n_devices, ACMPC_OK);
+  auto on_every_device = [&](auto&& body) {
+    std::vector<std::thread> threads;
+    threads.reserve((size_t)n_devices);
+    for (int g = 0; g < n_devices; ++g) threads.emplace_back([&, g] { rcs[(size_t)g] = body(g); });
+    for (std::thread& t : threads) t.join();
+    for (int g = 0; g < n_devices; ++g)
+      if (rcs[(size_t)g] != ACMPC_OK) {
+        if (ctxs[g] != ctx0) fail(ctx0, rcs[(size_t)g], "shard %d: %s", g, ctxs[g]->err);
+        return rcs[(size_t)g];
+      }
+    return (int)ACMPC_OK;
+  };
+  int rc = on_every_device([&](int g) -> int {
     acmpc_ctx* c = ctxs[g];
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t nl = l_cut[g + 1] - l_cut[g], no = o_cut[g + 1] - o_cut[g];
-    if ((rc = ensure(c, c->s_order_id, (size_t)nl))) return rc;
-    if ((rc = ensure(c, c->s_product_idx, (size_t)nl))) return rc;
-    if ((rc = ensure(c, c->s_qty, (size_t)nl))) return rc;
-    if ((rc = ensure(c, c->s_order_customer, (size_t)no))) return rc;
-    if ((rc = ensure(c, c->s_order_total, (size_t)no))) return rc;
-    if ((rc = ensure(c, c->s_merged, (size_t)n_merged))) return rc;
+    int r;
+    if ((r = ensure(c, c->s_order_id, (size_t)nl))) return r;
+    if ((r = ensure(c, c->s_product_idx, (size_t)nl))) return r;
+    if ((r = ensure(c, c->s_qty, (size_t)nl))) return r;
+    if ((r = ensure(c, c->s_order_customer, (size_t)no))) return r;
+    if ((r = ensure(c, c->s_order_total, (size_t)no))) return r;
+    if ((r = ensure(c, c->s_merged, (size_t)n_merged))) return r;
     hipStream_t st = nullptr;
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), st));
     if (nl > 0) {
@@ -1766,18 +1783,20 @@ ACMPC_API int acmpc_aggregate_sharded(acmpc_ctx* const* ctxs, acmpc_comm* const*
       HIPCHK(c, hipMemcpyAsync(c->s_qty.p, qty + l_cut[g], (size_t)nl * 4, hipMemcpyHostToDevice, st));
     }
     if (no > 0) HIPCHK(c, hipMemcpyAsync(c->s_order_customer.p, order_customer + o_cut[g], (size_t)no * 4, hipMemcpyHostToDevice, st));
-    rc = aggregate_device_impl(c, c->s_order_id.p, c->s_product_idx.p, c->s_qty.p, nl, c->s_order_customer.p, no,
-                               (int32_t)((int64_t)order_id_base + o_cut[g]), n_customers, c->s_order_total.p, c->s_merged.p,
-                               c->s_merged.p + P, st);
-    if (rc) { if (c != ctx0) fail(ctx0, rc, "shard %d: %s", g, c->err); return rc; }
-  }
+    return aggregate_device_impl(c, c->s_order_id.p, c->s_product_idx.p, c->s_qty.p, nl, c->s_order_customer.p, no,
+                                 (int32_t)((int64_t)order_id_base + o_cut[g]), n_customers, c->s_order_total.p, c->s_merged.p,
+                                 c->s_merged.p + P, st);
+  });
+  if (rc) return rc;
   // the one exchange: [product_qty | customer_total_cents], summed in place on every device
   {
     int64_t* bufs[kMaxDevices];
     for (int g = 0; g < n_devices; ++g) bufs[g] = ctxs[g]->s_merged.p;
     if ((rc = acmpc_merge_group_device(ctxs, comms, n_devices, bufs, n_merged, nullptr))) return rc;
   }
-  for (int g = 0; g < n_devices; ++g) {
+  // results back, and every device's verdict on its data (acmpc_status waits for the device)
+  std::vector<int> verdict((size_t)n_devices, ACMPC_OK);
+  rc = on_every_device([&](int g) -> int {
     acmpc_ctx* c = ctxs[g];
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t no = o_cut[g + 1] - o_cut[g];
@@ -1787,14 +1806,16 @@ ACMPC_API int acmpc_aggregate_sharded(acmpc_ctx* const* ctxs, acmpc_comm* const*
       HIPCHK(c, hipMemcpyAsync(out_product_qty, c->s_merged.p, (size_t)P * 8, hipMemcpyDeviceToHost, nullptr));
       HIPCHK(c, hipMemcpyAsync(out_customer_total_cents, c->s_merged.p + P, (size_t)n_customers * 8, hipMemcpyDeviceToHost, nullptr));
     }
-  }
-  uint32_t all = 0;
-  int worst = ACMPC_OK;
-  for (int g = 0; g < n_devices; ++g) {
     uint32_t flags = 0;
-    const int r = acmpc_status(ctxs[g], nullptr, &flags);   // waits for the device, collects its verdict on the data
-    all |= flags;
-    if (r != ACMPC_OK && worst == ACMPC_OK) { worst = r; if (ctxs[g] != ctx0) fail(ctx0, r, "shard %d: %s", g, ctxs[g]->err); }
-  }
+    verdict[(size_t)g] = acmpc_status(c, nullptr, &flags);
+    return ACMPC_OK;
+  });
+  if (rc) return rc;
+  int worst = ACMPC_OK;
+  for (int g = 0; g < n_devices; ++g)
+    if (verdict[(size_t)g] != ACMPC_OK && worst == ACMPC_OK) {
+      worst = verdict[(size_t)g];
+      if (ctxs[g] != ctx0) fail(ctx0, worst, "shard %d: %s", g, ctxs[g]->err);
+    }
   return worst;
 }
