@@ -27,7 +27,11 @@
  * maps a non-zero return to die(acmpc_last_error(ctx)).
  *
  * Threading: one context is used by one thread at a time.  Many processes may
- * each hold their own context on the same GPU.
+ * each hold their own context on the same GPU.  The host-pointer entry points
+ * start a few short-lived threads of their own while they copy more than 32 MiB
+ * (copies from and to pageable memory hold their calling thread; several at once
+ * cross the link faster), and acmpc_aggregate_sharded one per device; all have
+ * ended when the call returns.
  *
  * Limits (larger counts return ACMPC_E_INVALID): n_orders < 2^31 (order ids are
  * INT, store.sql:98,159), n_lines <= 2^40, n_products <= 2^28 (2^21 for a code
