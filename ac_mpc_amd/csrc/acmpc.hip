@@ -441,19 +441,20 @@ int launch_partition(acmpc_ctx* ctx, PartArgs& a, int blocks, hipStream_t st) {
   const size_t n = (size_t)std::max<int64_t>(a.n_lines, 1);
   for (int k = 0; k < 2; ++k)
     if ((rc = ensure(ctx, ctx->d_part_rec[k], n))) return rc;
-  const size_t n_meta = (size_t)kPartMaxBuckets * 3 + kPartCoarse + 24;
+  const size_t n_meta = (size_t)kPartMaxBuckets * 3 + kPartCoarse + 24;   // (+ 8 of bucket_off, changes, descents, mode)
   if ((rc = ensure(ctx, ctx->d_part_meta, n_meta))) return rc;
   a.counts = ctx->d_part_meta.p;
   a.bucket_off = a.counts + kPartMaxBuckets;
   a.cursor_b = a.bucket_off + kPartMaxBuckets + 8;
   a.cursor_a = a.cursor_b + kPartMaxBuckets;
   a.changes = a.cursor_a + kPartCoarse;
-  a.mode = a.changes + 1;
+  a.descents = a.changes + 1;
+  a.mode = a.changes + 2;
   a.rec_a = ctx->d_part_rec[0].p;
   a.rec_b = ctx->d_part_rec[1].p;
   a.n_buckets = (int32_t)((a.n_orders + kPartBucket - 1) / kPartBucket);
   HIPCHK(ctx, hipMemsetAsync(a.counts, 0, (size_t)kPartMaxBuckets * 8, st));
-  HIPCHK(ctx, hipMemsetAsync(a.changes, 0, 8, st));
+  HIPCHK(ctx, hipMemsetAsync(a.changes, 0, 16, st));     // changes and descents
   hipLaunchKernelGGL(k_part_count, dim3(blocks), dim3(kPartThreads), 0, st, a);
   hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(kPartThreads), 0, st, a);
   const size_t lds_a = (size_t)ctx->p_pad * 8 + kPartLdsA;
@@ -621,6 +622,8 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.order_state = d_state;
     a.no_hist = sp.use ? 1 : 0;
     a.run_if_zero = nullptr;
+    a.run_if_sorted = nullptr;
+    const unsigned long long* sorted_gate = nullptr;   // any-order rows: where the device says that they were grouped
 
     if (!fixed_ws) ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
     // rows in any order: the order-restoring path when the sizes allow it, else one global atomic per run
@@ -646,6 +649,11 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       const size_t tables = (size_t)ctx->p_pad * 8;     // (partition_fits: both tables in LDS, 32-bit prices)
       if ((rc = launch_lines_any<int32_t, true>(ctx, lp, tables, a, st))) return rc;
       a.run_if_zero = nullptr;
+      // ... or, if the ids never went down, the grouped kernel (its wave-boundary records are finished by k_fixup)
+      a.run_if_sorted = pa.mode;
+      if ((rc = launch_lines<int32_t, true, 4>(ctx, lp, a, st))) return rc;
+      a.run_if_sorted = nullptr;
+      sorted_gate = pa.mode;
     }
     else if (any_order) {
       HIPCHK(ctx, hipMemsetAsync(d_tot, 0, (size_t)n_orders * 8, st));
@@ -695,7 +703,8 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     f.base = base; f.n_orders = (int32_t)n_orders; f.order_total = d_tot; f.status = w.status;
     f.prod_slab = w.prod_slab; f.n_slabs = sp.use ? sp.n_streams : lp.blocks; f.p_pad = ctx->p_pad; f.n_products = P;
     f.merge_products = (lp.hist_lds || sp.use) ? 1 : 0;
-    f.fix_orders = any_order ? 0 : 1;
+    f.fix_orders = (any_order && !sorted_gate) ? 0 : 1;
+    f.fix_if_sorted = sorted_gate;
     f.prod_carry = w.prod_carry; f.product_qty = d_pq;
     f.ablate = ctx->ablate_fix;
     f.order_descuento = a.order_descuento; f.descuento_mode = a.descuento_mode;

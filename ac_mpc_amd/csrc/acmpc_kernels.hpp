@@ -79,8 +79,11 @@ struct LinesArgs {
   const int32_t* order_descuento;     // [M] or null (grouped kLife kernels): totals are stored net of it
   int32_t descuento_mode;
   // k_lines_any: when not null, the word in which the order-restoring path (acmpc_partition.hpp) says what it
-  // did: 0 nothing (this kernel runs in full), 1 everything (this kernel leaves), 2 the stock deltas only
+  // did: 0 nothing (this kernel runs in full), 1 everything (this kernel leaves), 2 the stock deltas only,
+  // 3 nothing, because the rows turned out to be grouped (this kernel leaves; the grouped kernel runs)
   const unsigned long long* run_if_zero;
+  // k_lines: when not null, run only if that word is 3
+  const unsigned long long* run_if_sorted;
 };
 
 // Lifecycle: quantities that reach the stock delta (0 for lines of orders that do not count).
@@ -459,6 +462,7 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
   static_assert(kLife || !kSnap, "line prices are a lifecycle column");
   constexpr int kTileL = kWave * LPL;                 // lines per wave-tile
   extern __shared__ __align__(16) unsigned char smem[];
+  if (a.run_if_sorted && *a.run_if_sorted != 3ull) return;   // uniform (rows in any order that were not grouped after all)
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
   const int waves_per_block = (int)(blockDim.x >> 6);
@@ -627,7 +631,7 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
   // run_if_zero names the word in which the order-restoring path says what it did: 0 = nothing (the rows are
   // near enough to grouped for this kernel), 1 = everything, 2 = the stock deltas but not the order totals
   const unsigned long long elsewhere = a.run_if_zero ? *a.run_if_zero : 0ull;
-  if (elsewhere == 1ull) return;                         // uniform
+  if (elsewhere == 1ull || elsewhere == 3ull) return;    // uniform
   const bool hist = !a.totals_only && !a.no_hist && elsewhere == 0ull;   // no_hist: k_stock does the stock deltas
   const bool price_lds = a.price_in_lds != 0;
   PriceT* s_price = reinterpret_cast<PriceT*>(smem);
@@ -757,7 +761,7 @@ __global__ void __launch_bounds__(1024) k_lines_any(LinesArgs a) {
 __global__ void __launch_bounds__(256) k_zero_if_unsorted(int64_t* out, int64_t n, const uint32_t* status, int need_unsorted,
                                                           const unsigned long long* run_if_zero) {
   if (need_unsorted && !(__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kStUnsorted)) return;
-  if (run_if_zero && *run_if_zero == 1ull) return;      // (the order-restoring path wrote every total)
+  if (run_if_zero && (*run_if_zero == 1ull || *run_if_zero == 3ull)) return;   // (another path writes every total)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = 0;
 }
 
@@ -782,6 +786,7 @@ struct FixArgs {
   int32_t n_products;
   int32_t merge_products;   // 1: blocks >= 1 merge the stock-delta slabs
   int32_t fix_orders;       // 1: block 0 finishes the orders cut by wave boundaries (grouped input)
+  const unsigned long long* fix_if_sorted;   // when not null: only if that word is 3 (see LinesArgs::run_if_sorted)
   unsigned long long* prod_carry;
   int64_t* product_qty;
   int32_t ablate;           // developer switch for timing experiments: 1 skip merge blocks, 2 skip block 0
@@ -848,6 +853,7 @@ __global__ void __launch_bounds__(kFixThreads) k_fixup(FixArgs a) {
     return;
   }
   if ((a.ablate & 2) || !a.fix_orders) return;
+  if (a.fix_if_sorted && *a.fix_if_sorted != 3ull) return;
   fixup_records(a, smem);
 }
 

@@ -62,7 +62,9 @@ struct PartArgs {
   // k_part_scan sets *mode to 1 (this path) when the estimate exceeds 0.4 changes per line, else to 0 (one
   // 64-bit atomic per run of equal ids, k_lines_any, which costs about 0.05 ms per million runs).  Pass A sets
   // it to 2 when it meets a value that does not fit a record: the atomic kernel then redoes the order totals.
+  // Rows whose ids never go down are grouped after all: mode 3, and the grouped line pass takes them.
   unsigned long long* changes;        // zero on entry of k_part_count
+  unsigned long long* descents;       // zero on entry of k_part_count; nonzero: the order id goes down somewhere
   unsigned long long* mode;
 };
 
@@ -72,7 +74,10 @@ __device__ __forceinline__ bool part_skip(const PartArgs& a) {
 // the scatter passes and the reduce: also when the rows are near enough to grouped for the atomic kernel
 __device__ __forceinline__ bool part_skip_moving(const PartArgs& a) { return part_skip(a) || *a.mode != 1ull; }
 // pass A itself may be the one that sets the mode to 2 while some of its workgroups have yet to start
-__device__ __forceinline__ bool part_skip_scatter_a(const PartArgs& a) { return part_skip(a) || *a.mode == 0ull; }
+__device__ __forceinline__ bool part_skip_scatter_a(const PartArgs& a) {
+  const unsigned long long m = *a.mode;
+  return part_skip(a) || m == 0ull || m == 3ull;
+}
 
 // A record: the order index in the 25 bits above the 39 bits of the line's value.
 constexpr int kPartValBits = 39;
@@ -128,15 +133,21 @@ __device__ __forceinline__ void part_rank_many(uint32_t* s_cnt, const uint32_t (
 // ---- lines per bucket ----------------------------------------------------------------------------
 __global__ void __launch_bounds__(kPartThreads) k_part_count(PartArgs a) {
   __shared__ uint32_t s_cnt[kPartMaxBuckets];
+  __shared__ uint32_t s_changes, s_descents;
   if (part_skip(a)) return;                               // uniform: the whole grid leaves
   for (int i = (int)threadIdx.x; i < kPartMaxBuckets; i += kPartThreads) s_cnt[i] = 0u;
+  if (threadIdx.x == 0) { s_changes = 0u; s_descents = 0u; }
   __syncthreads();
   uint32_t st = 0;
-  uint32_t changes = 0;
+  uint32_t changes = 0, descents = 0;
   const long long n4 = a.n_lines / 4;
-  auto take4 = [&](const int4& v) {
+  // Whether the ids ever go down is a yes or no: a wave that has met one place where they do stops looking
+  // (rows in no order at all pay for the comparisons of a wave's first lines only).
+  bool looking = true;                                      // uniform in the wave
+  auto take4 = [&](const int4& v, int before) {
     const int ids[4] = {v.x, v.y, v.z, v.w};
     changes += (v.x != v.y) + (v.y != v.z) + (v.z != v.w);
+    if (looking) descents += (before > v.x) + (v.x > v.y) + (v.y > v.z) + (v.z > v.w);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const uint32_t idx = (uint32_t)ids[i] - (uint32_t)a.base;
@@ -159,30 +170,51 @@ __global__ void __launch_bounds__(kPartThreads) k_part_count(PartArgs a) {
   const long long stride = (long long)gridDim.x * kPartThreads;
   const long long q0 = (long long)blockIdx.x * kPartThreads + (threadIdx.x & ~63u);      // the wave's first group
   const int lane = (int)(threadIdx.x & 63);
+  int vzero = 0;
+  asm volatile("" : "+v"(vzero));                       // 0, in a vector register
   for (long long qw = q0; qw < n4; qw += 4 * stride) {
     int4 v[4];
     bool in[4];
+    int front[4];                                            // the id in front of the wave's first line of a group
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const long long q = qw + (long long)k * stride + lane;
+      const long long qg = qw + (long long)k * stride;       // (uniform in the wave)
+      const long long q = qg + lane;
       in[k] = q < n4;
       v[k] = in[k] ? load_stream16(a.order_id + 4 * q) : make_int4(0, 0, 0, 0);
+      // (read as a vector load like the others: as a scalar load its wait would also wait for the LDS adds)
+      front[k] = (looking && qg > 0 && qg < n4) ? a.order_id[4 * qg - 1 + vzero] : 0;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (in[k]) take4(v[k]);                               // (the ballots in there count the lanes that are here)
+      // the id in front of a lane's four: the last of the lane below, or (lane 0) the one in front of the group;
+      // the very first line of the data has none
+      int before = v[k].x;
+      if (looking) {
+        const int below = wave_shift_up1(v[k].w, front[k]);
+        const bool first_line = lane == 0 && qw + (long long)k * stride == 0;
+        if (!first_line) before = below;
+      }
+      if (in[k]) take4(v[k], before);                        // (the ballots in there count the lanes that are here)
     }
+    if (looking) looking = __ballot(descents != 0u) == 0ull;
   }
   if (blockIdx.x == 0 && (long long)threadIdx.x < a.n_lines - 4 * n4) {
+    const long long l = 4 * n4 + threadIdx.x;
+    if (l > 0 && a.order_id[l - 1] > a.order_id[l]) ++descents;
     const uint32_t idx = (uint32_t)a.order_id[4 * n4 + threadIdx.x] - (uint32_t)a.base;
     if (idx < (uint32_t)a.n_orders) __hip_atomic_fetch_add(&s_cnt[idx >> kPartShift], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else st |= kStOrderRange;
   }
   if (st) atomicOr(a.status, st);
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) changes += __shfl_xor(changes, d);
-  if ((threadIdx.x & 63) == 0 && changes) atomicAdd(a.changes, (unsigned long long)changes);
+  for (int d = 32; d > 0; d >>= 1) { changes += __shfl_xor(changes, d); descents += __shfl_xor(descents, d); }
+  // one add per workgroup: thousands of waves adding to one address wait for each other
+  if ((threadIdx.x & 63) == 0 && changes) __hip_atomic_fetch_add(&s_changes, changes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if ((threadIdx.x & 63) == 0 && descents) s_descents = 1u;
   __syncthreads();
+  if (threadIdx.x == 0 && s_changes) atomicAdd(a.changes, (unsigned long long)s_changes);
+  if (threadIdx.x == 0 && s_descents) *a.descents = 1ull;   // (a yes or no: every writer stores the same)
   for (int i = (int)threadIdx.x; i < a.n_buckets; i += kPartThreads)
     if (s_cnt[i]) atomicAdd(&a.counts[i], (unsigned long long)s_cnt[i]);
 }
@@ -210,8 +242,9 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scan(PartArgs a) {
   if (tid == 0) {
     // three of every four places were looked at: changes per line is about (4/3) * counted / n_lines
     const unsigned long long c = *a.changes;
-    *a.mode = (c * 10ull > (unsigned long long)a.n_lines * 3ull) ? 1ull : 0ull;
+    *a.mode = *a.descents == 0ull ? 3ull : (c * 10ull > (unsigned long long)a.n_lines * 3ull) ? 1ull : 0ull;
     *a.changes = 0ull;
+    *a.descents = 0ull;
   }
 }
 

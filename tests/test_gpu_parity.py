@@ -522,6 +522,32 @@ def test_any_line_order_values_that_do_not_fit_a_record(motor, oracle, what):
     _check_any_order(motor, oracle, oid[perm], pidx[perm], qty[perm], d["order_customer"], 5, c, price)
 
 
+@pytest.mark.parametrize("align", [1, 4, 256, 4096, 2048 * 4096, "tail", "first"])
+def test_any_order_one_descent_where_the_counting_pass_changes_hands(motor, oracle, align):
+    """Rows whose ids never go down are handed to the grouped kernel; a single swapped pair must be seen wherever it
+    lies: inside a lane's four ids, between lanes, between waves, between workgroups, between the sweeps of the
+    grid, among the last lines (the count is not a multiple of 4) and at the very start."""
+    n = 9_000_003
+    d = oracle.synth(n, 10_000, 100_000, qty_mode=1)
+    oid, pidx, qty = d["order_id"].copy(), d["product_idx"].copy(), d["qty"].copy()
+    if align == "tail":
+        oid[n - 1] = oid[n - 2] - 1                          # the last row belongs to the order before
+    elif align == "first":
+        k = 0
+        while oid[k] == oid[k + 1]:
+            k += 1
+        for col in (oid, pidx, qty):                          # the first order's rows go behind the second's first row
+            col[0], col[k + 1] = col[k + 1], col[0]
+    else:
+        k = align * max(1, 1_234_567 // align) - 1          # rows k, k + 1 lie either side of a multiple of `align`
+        while oid[k] == oid[k + 1]:
+            k += align
+        for col in (oid, pidx, qty):
+            col[k], col[k + 1] = col[k + 1], col[k]
+    assert np.any(np.diff(oid) < 0)
+    _check_any_order(motor, oracle, oid, pidx, qty, d["order_customer"], 5, 100_000, oracle.synth_prices(10_000))
+
+
 def test_grouped_mode_still_rejects_shuffled_rows(motor, oracle):
     d = oracle.synth(50_000, 100, 50)
     perm = np.random.default_rng(31).permutation(50_000)
