@@ -75,6 +75,8 @@ __device__ __forceinline__ unsigned long long emit_abs(long long v) {
 // [-]units.cc of an amount in cents
 __device__ __forceinline__ int emit_amount_len(long long cents) {
   const unsigned long long m = emit_abs(cents);
+  if (m <= 0xffffffffull)                                    // (the common case without a 64-bit division)
+    return (cents < 0) + emit_digits32(__umulhi((uint32_t)m, 1374389535u) >> 5) + 3;
   return (cents < 0) + emit_digits(m / 100ull) + 3;
 }
 
@@ -233,6 +235,132 @@ struct EmitRow<kEmitStock, kEmitCsv> {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Word-wide formatting of the common totals row: an amount of 0 .. 2^32 - 1 cents and an order id below 10^8.
+// The row is put together as three byte strings with a fixed layout each (the units and the id are made
+// left-aligned by scaling them to eight digits first, so nothing in a string moves with a digit count; only
+// where the second and third string start does), and every string is OR-ed into the zeroed LDS batch a word
+// at a time, shifted to its byte position: a word shared by two neighbouring rows takes both.  Any other row
+// (negative or larger amount, longer id) sends its whole wave through the byte-wise formatter above.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t emit_w4(const char* s, int i) {
+  return (uint32_t)(unsigned char)s[i] | ((uint32_t)(unsigned char)s[i + 1] << 8) |
+         ((uint32_t)(unsigned char)s[i + 2] << 16) | ((uint32_t)(unsigned char)s[i + 3] << 24);
+}
+
+// x < 10000 -> its four decimal digits as ASCII, most significant in the lowest byte.
+__device__ __forceinline__ uint32_t emit_ascii4(uint32_t x) {
+  const uint32_t a = (x * 5243u) >> 19;                     // x / 100 (exact below 10000)
+  const uint32_t y2 = a | ((x - a * 100u) << 16);           // two numbers below 100 side by side
+  const uint32_t t2 = ((y2 * 205u) >> 11) & 0x000F000Fu;    // their tens (y * 205 >> 11 == y / 10 below 100)
+  const uint32_t o2 = y2 - t2 * 10u;                        // their ones
+  return (t2 | (o2 << 8)) + 0x30303030u;
+}
+
+// The low n bytes of a word (n <= 0: none, n >= 4: all).
+__device__ __forceinline__ uint32_t emit_keep(int n) {
+  n = min(max(n, 0), 4);
+  return (uint32_t)((1ull << (8 * n)) - 1ull);
+}
+
+// v < 10^8 -> its nd decimal digits left-aligned in two words (bytes past the digits are zero).
+struct EmitDigits { uint32_t w0, w1; int nd; };
+__device__ __forceinline__ EmitDigits emit_left_digits(uint32_t v) {
+  int nd = 8;
+  if (v < 10000u) { v *= 10000u; nd -= 4; }
+  if (v < 1000000u) { v *= 100u; nd -= 2; }
+  if (v < 10000000u) { v *= 10u; nd -= 1; }                 // (0 ends here as 0 with one digit)
+  const uint32_t hi = __umulhi(v, 3518437209u) >> 13;       // v / 10000 (exact below 2^32)
+  const uint32_t lo = v - hi * 10000u;
+  EmitDigits d;
+  d.nd = nd;
+  d.w0 = emit_ascii4(hi) & emit_keep(nd);
+  d.w1 = emit_ascii4(lo) & emit_keep(nd - 4);
+  return d;
+}
+
+// OR the byte string held in w[0..N) (zero past its end) into the LDS text at byte `pos`: N + 1 words.
+// (`s` has at least four bytes of slack in front of position 0.)
+template <int N>
+__device__ __forceinline__ void emit_or_words(unsigned char* s, int pos, const uint32_t (&w)[N]) {
+  // word i of the shifted string is {w[i], w[i-1]} >> 8 * ((4 - pos) & 3); with pos a multiple of 4 that is
+  // w[i-1], one word late: the words then start one word earlier
+  uint32_t* dst = reinterpret_cast<uint32_t*>(s) + ((pos + 3) >> 2) - 1;
+  const uint32_t k = (uint32_t)(4 - (pos & 3)) & 3u;
+  uint32_t prev = 0u;
+#pragma unroll
+  for (int i = 0; i <= N; ++i) {
+    const uint32_t cur = i < N ? w[i] : 0u;
+    const uint32_t t = __builtin_amdgcn_alignbyte(cur, prev, k);
+    __hip_atomic_fetch_or(dst + i, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    prev = cur;
+  }
+}
+
+// What the fast formatter keeps of a row between the length scan and the write.
+struct EmitFastRow { EmitDigits units, id; uint32_t frac; };
+
+__device__ __forceinline__ bool emit_fast_ok(long long cents, long long id) {
+  return (unsigned long long)cents <= 0xffffffffull && (unsigned long long)id < 100000000ull;
+}
+__device__ __forceinline__ EmitFastRow emit_fast_prepare(uint32_t cents, uint32_t id) {
+  const uint32_t units = __umulhi(cents, 1374389535u) >> 5;   // cents / 100 (exact below 2^32)
+  EmitFastRow f;
+  f.frac = cents - units * 100u;
+  f.units = emit_left_digits(units);
+  f.id = emit_left_digits(id);
+  return f;
+}
+// ".cc" as three bytes in the low end of a word
+__device__ __forceinline__ uint32_t emit_frac3(uint32_t frac) {
+  const uint32_t t = (frac * 205u) >> 11;
+  return 0x0030302Eu + (t << 8) + ((frac - t * 10u) << 16);
+}
+
+template <int Style>
+struct EmitFast;
+
+template <>
+struct EmitFast<kEmitSql> {
+  static constexpr char kLit1[] = "update venta set TotalPagar=";       // 28 bytes; the quote goes with the digits
+  static constexpr char kLit2[] = " where NumPedido";                   // 16 bytes between "'" and "='"
+  static __device__ __forceinline__ int len(const EmitFastRow& f) { return 29 + f.units.nd + 3 + 19 + f.id.nd + 3; }
+  static __device__ __forceinline__ void put(const EmitFastRow& f, unsigned char* s, int p) {
+    uint32_t a[10];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) a[i] = emit_w4(kLit1, 4 * i);
+    a[7] = 0x27u | (f.units.w0 << 8);
+    a[8] = __builtin_amdgcn_alignbyte(f.units.w1, f.units.w0, 3);
+    a[9] = f.units.w1 >> 24;
+    emit_or_words<10>(s, p, a);
+    uint32_t b[8];
+    b[0] = emit_frac3(f.frac) | 0x27000000u;                              // .cc'
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[1 + i] = emit_w4(kLit2, 4 * i);
+    b[5] = 0x0000273Du | (f.id.w0 << 16);                                 // ='
+    b[6] = (f.id.w0 >> 16) | (f.id.w1 << 16);
+    b[7] = f.id.w1 >> 16;
+    const int pb = p + 29 + f.units.nd;
+    emit_or_words<8>(s, pb, b);
+    const uint32_t c[1] = {0x000A3B27u};                                  // ';\n
+    emit_or_words<1>(s, pb + 22 + f.id.nd, c);
+  }
+};
+
+template <>
+struct EmitFast<kEmitCsv> {
+  static __device__ __forceinline__ int len(const EmitFastRow& f) { return f.id.nd + 1 + f.units.nd + 4; }
+  static __device__ __forceinline__ void put(const EmitFastRow& f, unsigned char* s, int p) {
+    const uint32_t a[2] = {f.id.w0, f.id.w1};
+    emit_or_words<2>(s, p, a);
+    const uint32_t b[3] = {0x2Cu | (f.units.w0 << 8), __builtin_amdgcn_alignbyte(f.units.w1, f.units.w0, 3), f.units.w1 >> 24};
+    const int pb = p + f.id.nd;
+    emit_or_words<3>(s, pb, b);
+    const uint32_t c[1] = {emit_frac3(f.frac) | 0x0A000000u};            // .cc\n
+    emit_or_words<1>(s, pb + 1 + f.units.nd, c);
+  }
+};
+
 // Inclusive scan of one int per thread over the workgroup; returns the exclusive prefix and the total.
 __device__ __forceinline__ int emit_block_scan(int v, int* s_w, int& total) {
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -256,9 +384,14 @@ __global__ void __launch_bounds__(kEmitThreads) k_emit_count(EmitArgs a) {
   for (int64_t c = blockIdx.x; c < a.n_chunks; c += gridDim.x) {
     const int64_t r0 = c * kEmitChunkRows;
     long long sum = 0;
-    for (int b = 0; b < kEmitChunkRows / kEmitThreads; ++b) {
-      const int64_t r = r0 + b * kEmitThreads + tid;
-      if (r < a.n_rows) sum += EmitRow<Kind, Style>::len(a, r);
+    if (r0 + kEmitChunkRows <= a.n_rows) {                   // uniform: every chunk but the last
+#pragma unroll
+      for (int b = 0; b < kEmitChunkRows / kEmitThreads; ++b) sum += EmitRow<Kind, Style>::len(a, r0 + b * kEmitThreads + tid);
+    } else {
+      for (int b = 0; b < kEmitChunkRows / kEmitThreads; ++b) {
+        const int64_t r = r0 + b * kEmitThreads + tid;
+        if (r < a.n_rows) sum += EmitRow<Kind, Style>::len(a, r);
+      }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
@@ -315,19 +448,43 @@ __global__ void __launch_bounds__(1024) k_chunk_scan(ScanArgs a) {
 
 template <int Kind, int Style>
 __global__ void __launch_bounds__(kEmitThreads) k_emit_write(EmitArgs a) {
-  __shared__ __align__(16) unsigned char s_out[16 + kEmitThreads * kEmitMaxRow + 16];
+  // [16 bytes in front][a batch of rows, from byte gofs % 16 on][slack]: words OR-ed in may reach a few bytes
+  // past either end of a row.  Zero between batches: the copy-out clears what it has read.
+  constexpr int kBuf = 16 + 16 + kEmitThreads * kEmitMaxRow + 48;
+  __shared__ __align__(16) unsigned char s_buf[kBuf];
   __shared__ int s_w[kEmitThreads / 64];
+  unsigned char* s_out = s_buf + 16;
+  constexpr bool kFast = Kind == kEmitTotals && (Style == kEmitSql || Style == kEmitCsv);
+  using Fast = EmitFast<(Kind == kEmitTotals && Style == kEmitCsv) ? kEmitCsv : kEmitSql>;
   const int tid = (int)threadIdx.x;
+  for (int i = tid * 16; i < kBuf; i += kEmitThreads * 16) *reinterpret_cast<uint4*>(s_buf + i) = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
   for (int64_t c = blockIdx.x; c < a.n_chunks; c += gridDim.x) {
     long long gofs = a.chunk_bytes[c];
     for (int b = 0; b < kEmitChunkRows / kEmitThreads; ++b) {
       const int64_t r = c * kEmitChunkRows + b * kEmitThreads + tid;
-      const int len = r < a.n_rows ? EmitRow<Kind, Style>::len(a, r) : 0;
+      const bool in = r < a.n_rows;
+      int len = 0;
+      bool fast = false;                                  // uniform in the wave
+      EmitFastRow f = {};
+      if (kFast) {
+        const long long v = in ? a.value[r] : 0;
+        const long long id = in ? a.order_id_base + r : 0;
+        fast = __ballot(!emit_fast_ok(v, id)) == 0ull;
+        if (fast) {
+          f = emit_fast_prepare((uint32_t)v, (uint32_t)id);
+          len = in ? Fast::len(f) : 0;
+        }
+      }
+      if (!fast) len = in ? EmitRow<Kind, Style>::len(a, r) : 0;
       int total;
       const int off = emit_block_scan(len, s_w, total);
       if (total == 0) continue;                       // uniform: every thread sees the same total
       const int shift = (int)(gofs & 15);
-      if (len) EmitRow<Kind, Style>::put(a, r, s_out, shift + off);
+      if (len) {
+        if (kFast && fast) Fast::put(f, s_out, shift + off);
+        else EmitRow<Kind, Style>::put(a, r, s_out, shift + off);
+      }
       __syncthreads();
       // LDS byte i sits at text[g0 + i]; g0 is a multiple of 16
       const long long g0 = gofs - shift;
@@ -340,6 +497,7 @@ __global__ void __launch_bounds__(kEmitThreads) k_emit_write(EmitArgs a) {
           const int from = lo < shift ? shift : lo, to = hi < end ? hi : end;
           for (int i = from; i < to; ++i) if (g0 + i < a.capacity) a.text[g0 + i] = s_out[i];
         }
+        *reinterpret_cast<uint4*>(s_out + lo) = make_uint4(0u, 0u, 0u, 0u);
       }
       __syncthreads();
       gofs += total;

@@ -27,6 +27,25 @@ def test_totals_sizes(motor, oracle, em, style, n, base):
     assert em.totales(motor, vals, base, style) == oracle.emit_totals(vals, base, style)
 
 
+@pytest.mark.parametrize("style", [0, 1, 2])
+@pytest.mark.parametrize("base", [0, 5, 9_990, 99_999_000, 99_999_999, 100_000_000])
+def test_totals_common_rows_with_a_few_others_between(motor, oracle, em, style, base):
+    """Amounts of 0 .. 2^32 - 1 cents with ids below 10^8 are formatted a word at a time, a whole wave of them
+    together; a wave that holds any other row is formatted byte by byte.  Every digit count of both numbers, the
+    limits of the common case, waves of either kind side by side in a batch, ids that cross 10^8 on the way."""
+    rng = np.random.default_rng(41 + style)
+    n = 20_011
+    mag = rng.integers(0, 33, size=n)
+    vals = (rng.integers(0, 2**32, size=n, dtype=np.int64) >> (32 - mag)).astype(np.int64)
+    vals[:12] = [0, 1, 9, 10, 99, 100, 101, 999, 1000, 2**32 - 1, 2**32 - 2, 4_294_967_200]
+    for k in range(2, 10):
+        vals[20 + 3 * k: 23 + 3 * k] = [10**k - 1, 10**k, 10**k + 1]
+    vals[[700, 701, 5_000, 12_345, 20_010]] = [2**32, -1, -220000, 2**40, 2**63 - 1]      # these waves go byte by byte
+    text = em.totales(motor, vals, base, style)
+    assert text == oracle.emit_totals(vals, base, style)
+    assert text.startswith(ec.totals_text(vals[:200].tolist(), base, style))
+
+
 def test_totals_empty_and_bad_arguments(motor, em):
     from ac_mpc_amd import ErrorLote
     assert em.totales(motor, np.zeros(0, np.int64), 5) == b""
