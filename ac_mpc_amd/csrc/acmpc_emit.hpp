@@ -446,11 +446,19 @@ __global__ void __launch_bounds__(1024) k_chunk_scan(ScanArgs a) {
   }
 }
 
+// Rows a thread formats per batch (consecutive rows, so that its text is one piece), and the longest row: short
+// rows are taken several at a time, or the four barriers of a batch would cost more than its bytes.
+template <int Kind, int Style> struct EmitBatch { static constexpr int kRows = 1, kMaxRow = kEmitMaxRow; };
+template <> struct EmitBatch<kEmitTotals, kEmitCsv> { static constexpr int kRows = 4, kMaxRow = 36; };   // "-2147483648,-92233720368547758.08\n"
+
 template <int Kind, int Style>
 __global__ void __launch_bounds__(kEmitThreads) k_emit_write(EmitArgs a) {
   // [16 bytes in front][a batch of rows, from byte gofs % 16 on][slack]: words OR-ed in may reach a few bytes
   // past either end of a row.  Zero between batches: the copy-out clears what it has read.
-  constexpr int kBuf = 16 + 16 + kEmitThreads * kEmitMaxRow + 48;
+  constexpr int R = EmitBatch<Kind, Style>::kRows;
+  constexpr int kBatchRows = kEmitThreads * R;
+  static_assert(kEmitChunkRows % kBatchRows == 0, "whole batches per chunk");
+  constexpr int kBuf = 16 + 16 + kBatchRows * EmitBatch<Kind, Style>::kMaxRow + 48;
   __shared__ __align__(16) unsigned char s_buf[kBuf];
   __shared__ int s_w[kEmitThreads / 64];
   unsigned char* s_out = s_buf + 16;
@@ -461,29 +469,48 @@ __global__ void __launch_bounds__(kEmitThreads) k_emit_write(EmitArgs a) {
   __syncthreads();
   for (int64_t c = blockIdx.x; c < a.n_chunks; c += gridDim.x) {
     long long gofs = a.chunk_bytes[c];
-    for (int b = 0; b < kEmitChunkRows / kEmitThreads; ++b) {
-      const int64_t r = c * kEmitChunkRows + b * kEmitThreads + tid;
-      const bool in = r < a.n_rows;
-      int len = 0;
+    for (int b = 0; b < kEmitChunkRows / kBatchRows; ++b) {
+      const int64_t r0 = c * kEmitChunkRows + (int64_t)b * kBatchRows + (int64_t)tid * R;     // this thread's first row
+      int len[R];
+      int mine = 0;
       bool fast = false;                                  // uniform in the wave
-      EmitFastRow f = {};
+      EmitFastRow f[R];
       if (kFast) {
-        const long long v = in ? a.value[r] : 0;
-        const long long id = in ? a.order_id_base + r : 0;
-        fast = __ballot(!emit_fast_ok(v, id)) == 0ull;
+        long long v[R];
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const bool in = r0 + j < a.n_rows;
+          v[j] = in ? a.value[r0 + j] : 0;
+          ok = ok && emit_fast_ok(v[j], in ? a.order_id_base + r0 + j : 0);
+        }
+        fast = __ballot(!ok) == 0ull;
         if (fast) {
-          f = emit_fast_prepare((uint32_t)v, (uint32_t)id);
-          len = in ? Fast::len(f) : 0;
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            f[j] = emit_fast_prepare((uint32_t)v[j], (uint32_t)(a.order_id_base + r0 + j));
+            len[j] = r0 + j < a.n_rows ? Fast::len(f[j]) : 0;
+          }
         }
       }
-      if (!fast) len = in ? EmitRow<Kind, Style>::len(a, r) : 0;
+      if (!fast) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) len[j] = r0 + j < a.n_rows ? EmitRow<Kind, Style>::len(a, r0 + j) : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < R; ++j) mine += len[j];
       int total;
-      const int off = emit_block_scan(len, s_w, total);
+      const int off = emit_block_scan(mine, s_w, total);
       if (total == 0) continue;                       // uniform: every thread sees the same total
       const int shift = (int)(gofs & 15);
-      if (len) {
-        if (kFast && fast) Fast::put(f, s_out, shift + off);
-        else EmitRow<Kind, Style>::put(a, r, s_out, shift + off);
+      int p = shift + off;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        if (len[j]) {
+          if (kFast && fast) Fast::put(f[j], s_out, p);
+          else EmitRow<Kind, Style>::put(a, r0 + j, s_out, p);
+        }
+        p += len[j];
       }
       __syncthreads();
       // LDS byte i sits at text[g0 + i]; g0 is a multiple of 16
