@@ -438,7 +438,7 @@ bool partition_fits(const acmpc_ctx* ctx, const LinesPlan& lp, int64_t n_orders)
 
 int launch_partition(acmpc_ctx* ctx, PartArgs& a, int blocks, hipStream_t st) {
   int rc;
-  const size_t n = (size_t)std::max<int64_t>(a.n_lines, 1);
+  const size_t n = ((size_t)std::max<int64_t>(a.n_lines, 1) + 1) & ~(size_t)1;     // (the reduce reads whole pairs of records)
   for (int k = 0; k < 2; ++k)
     if ((rc = ensure(ctx, ctx->d_part_rec[k], n))) return rc;
   const size_t n_meta = (size_t)kPartMaxBuckets * 3 + kPartCoarse + 24;   // (+ 8 of bucket_off, changes, descents, mode)

@@ -468,21 +468,29 @@ __global__ void __launch_bounds__(kPartThreads) k_part_reduce(PartArgs a) {
   for (int i = tid * 2; i < kPartBucket; i += kPartThreads * 2) *reinterpret_cast<uint4*>(s_tab + i) = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   const long long lo = (long long)a.bucket_off[b], hi = (long long)a.bucket_off[b + 1];
-  // eight records a thread in flight (a bucket starts anywhere, so single 8-byte loads; consecutive lanes
-  // read consecutive records)
+  // Sixteen records a thread in flight, as eight streaming 16-byte loads of two records each (a bucket starts at
+  // any record: the pairs are taken from the even record at or below it, and records outside [lo, hi) are skipped).
   constexpr int kDepth = 8;
-  for (long long e = lo + tid; e < hi; e += kDepth * kPartThreads) {
-    unsigned long long rec[kDepth];
+  const long long lo2 = lo & ~1ll;
+  for (long long e = lo2 + 2 * tid; e < hi; e += 2 * kDepth * kPartThreads) {
+    long long rec[kDepth][2];
 #pragma unroll
     for (int k = 0; k < kDepth; ++k) {
-      const long long ek = e + (long long)k * kPartThreads;
-      rec[k] = ek < hi ? a.rec_b[ek] : 0ull;
+      const long long ek = e + 2ll * k * kPartThreads;
+      if (ek < hi) load_prices<2>(reinterpret_cast<const long long*>(a.rec_b + ek), rec[k]);   // (the workspace ends on an even record)
+      else rec[k][0] = rec[k][1] = 0;
     }
 #pragma unroll
-    for (int k = 0; k < kDepth; ++k)
-      if (e + (long long)k * kPartThreads < hi)
-        __hip_atomic_fetch_add(&s_tab[(rec[k] >> kPartValBits) & (kPartBucket - 1)], rec[k] & kPartValMask, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int k = 0; k < kDepth; ++k) {
+      const long long ek = e + 2ll * k * kPartThreads;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned long long r = (unsigned long long)rec[k][j];
+        if (ek + j >= lo && ek + j < hi)
+          __hip_atomic_fetch_add(&s_tab[(r >> kPartValBits) & (kPartBucket - 1)], r & kPartValMask, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
   }
   __syncthreads();
   const long long o0 = (long long)b * kPartBucket;
