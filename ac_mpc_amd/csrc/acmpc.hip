@@ -129,6 +129,7 @@ struct acmpc_ctx {
   int k1_lpl = 4;
   int k2_threads = 1024;
   int k1_burst = 2;             // tiles between synchronised output bursts of k_lines (0 = off)
+  int k1_tpw = 0;               // developer switch: at least this many tiles per wave in k_lines (ACMPC_K1_TPW)
   int k1_cus = 0, k2_cus = 0;   // developer switches: pretend the device has this many CUs (0 = all)
   // developer switches for timing experiments: parts of a kernel are skipped and its results are WRONG.
   // Read once at init, and only when ACMPC_DEV_ABLATE=1 is set as well.
@@ -308,6 +309,7 @@ int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p, bool line_pr
   p->n_tiles = (n_lines + p->tile_lines - 1) / p->tile_lines;
   const int64_t max_waves = (int64_t)max_blocks * p->waves_per_block;
   p->tiles_per_wave = std::max<int64_t>(1, (p->n_tiles + max_waves - 1) / max_waves);
+  if (ctx->k1_tpw > 0) p->tiles_per_wave = std::max<int64_t>(p->tiles_per_wave, ctx->k1_tpw);   // developer switch
   p->n_active_waves = (int)((p->n_tiles + p->tiles_per_wave - 1) / p->tiles_per_wave);
   p->blocks = std::max(1, (p->n_active_waves + p->waves_per_block - 1) / p->waves_per_block);
   return ACMPC_OK;
@@ -902,6 +904,7 @@ ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
   }
   ctx->k1_burst = std::max(0, env_int("ACMPC_K1_BURST", 2));
   ctx->k1_cus = env_int("ACMPC_K1_CUS", 0);
+  ctx->k1_tpw = env_int("ACMPC_K1_TPW", 0);
   ctx->k2_cus = env_int("ACMPC_K2_CUS", 0);
   if (ctx->k2_threads != 256 && ctx->k2_threads != 512 && ctx->k2_threads != 1024) ctx->k2_threads = 1024;
   ctx->force_global_tables = env_int("ACMPC_FORCE_GLOBAL_TABLES", 0);
