@@ -1086,10 +1086,16 @@ struct CustArgs {
   const unsigned char* order_state;   // [M] or null (kLife kernels): bit 0 = the order counts
 };
 
-// One tile of 256 orders: lane l holds orders 4l..4l+3 in (cs, tv).
+// One tile of 256 orders: lane l holds orders 4l..4l+3 in (cs, tv).  `s_scratch` is this lane's own scratch
+// word; `check_ids` (uniform) says whether this workgroup is the one of its stream that reports customer ids
+// outside the table.
+// The pass is bound by instruction issue (a sibling workgroup runs this for every order of its stream, two
+// thirds of which belong to other ranges), so the common path is kept to a subtract, a compare, an address, a
+// select and the add per order, and one carry test afterwards; anything else sends the lane down the exact path.
 template <bool kLdsTables>
-__device__ __forceinline__ void customers_tile(const CustArgs& a, uint32_t* s_tab, uint32_t* s_dummy, int lo, int len,
-                                               const int (&cs)[4], const long long (&tv)[4], int lane, uint32_t& st) {
+__device__ __forceinline__ void customers_tile(const CustArgs& a, uint32_t* s_tab, uint32_t* s_scratch, int lo, int len,
+                                               bool check_ids, const int (&cs)[4], const long long (&tv)[4],
+                                               uint32_t& st) {
   if (!kLdsTables) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1100,8 +1106,9 @@ __device__ __forceinline__ void customers_tile(const CustArgs& a, uint32_t* s_ta
   }
   // 32-bit partial sums in LDS; the add returns the old word so that a carry out of bit 31 (and the
   // high half of a total of 2^32 cents or more) can be forwarded to a 64-bit global cell.  All four
-  // adds are issued before the first result is needed; orders of other ranges add 0 to a scratch word.
-  uint32_t old[4], add[4];
+  // adds are issued before the first result is needed; an order of another range adds to the lane's scratch
+  // word, whose contents nobody reads.
+  uint32_t old[4];
   bool inr[4];
   if (a.ablate & 1) {
     if ((cs[0] ^ cs[1] ^ cs[2] ^ cs[3] ^ (int)tv[0] ^ (int)tv[1] ^ (int)tv[2] ^ (int)tv[3]) == 0x7ffffff1) st |= 8u;
@@ -1111,23 +1118,26 @@ __device__ __forceinline__ void customers_tile(const CustArgs& a, uint32_t* s_ta
   for (int i = 0; i < 4; ++i) {
     const uint32_t off = (uint32_t)(cs[i] - lo);
     inr[i] = off < (uint32_t)len;
-    add[i] = inr[i] ? (uint32_t)tv[i] : 0u;
-    uint32_t* cell = inr[i] ? (s_tab + off) : (s_dummy + lane);
-    old[i] = __hip_atomic_fetch_add(cell, add[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t* cell = inr[i] ? (s_tab + off) : s_scratch;
+    old[i] = __hip_atomic_fetch_add(cell, (uint32_t)tv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  uint32_t rare = 0;
+  bool rare = false;
+  uint32_t high = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const bool carry = (uint32_t)(old[i] + add[i]) < old[i];
-    const bool high = inr[i] && ((tv[i] >> 32) != 0 || carry);
-    rare |= high ? 1u : 0u;
-    rare |= ((uint32_t)cs[i] >= (uint32_t)a.n_customers) ? 2u : 0u;
+    rare |= inr[i] && (uint32_t)(old[i] + (uint32_t)tv[i]) < old[i];
+    high |= (uint32_t)((unsigned long long)tv[i] >> 32);
+  }
+  rare |= high != 0u;
+  if (check_ids) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rare |= (uint32_t)cs[i] >= (uint32_t)a.n_customers;
   }
   if (rare) {
-    if (rare & 2u) st |= kStCustomerRange;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long carry = ((uint32_t)(old[i] + add[i]) < old[i]) ? 1 : 0;
+      if ((uint32_t)cs[i] >= (uint32_t)a.n_customers) st |= kStCustomerRange;
+      const long long carry = ((uint32_t)(old[i] + (uint32_t)tv[i]) < old[i]) ? 1 : 0;
       const long long hi = (tv[i] >> 32) + carry;
       if (inr[i] && hi != 0) atomicAdd(&a.cust_carry[cs[i]], ((unsigned long long)hi) << 32);
     }
@@ -1174,12 +1184,14 @@ __global__ void __launch_bounds__(1024) k_customers_fused(CustFusedArgs a) {
 template <bool kLdsTables, bool kLife>
 __device__ __forceinline__ void customers_block(const CustArgs& a, unsigned char* smem, int bid) {
   uint32_t* s_tab = reinterpret_cast<uint32_t*>(smem);
-  uint32_t* s_dummy = s_tab + a.span;
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
+  uint32_t* s_scratch = s_tab + a.span + lane;
+  // (the wave's number in a scalar register: tile numbers and addresses are then scalar arithmetic)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int waves_per_block = (int)(blockDim.x >> 6);
   const int x = bid & 7, jslot = bid >> 3;
   const int r = jslot % a.n_ranges;
+  const bool check_ids = r == 0;                           // one workgroup of a stream reports ids outside the table
   const int s = x + 8 * (jslot / a.n_ranges);
   const int lo = r * a.span;
   int len = a.n_customers - lo;
@@ -1199,52 +1211,59 @@ __device__ __forceinline__ void customers_block(const CustArgs& a, unsigned char
   const long long n_full = a.n_orders / kTile;
   const long long tf = t1 < n_full ? t1 : n_full;         // complete tiles of this stream: [t0, tf)
 
-  long long t = t0 + wave;
-  if (t < tf && !(a.ablate & 2)) {
+  if (t0 + wave < tf && !(a.ablate & 2)) {
     // Software pipeline over this wave's tiles (t, t + W, t + 2W, ...) with kCustDepth tiles in
     // flight: most of these loads are L2 hits shared with the sibling workgroups, and a CU needs
     // far more bytes in flight to stream from L2 than to stream its share of HBM.  Loads past the
     // wave's last tile re-read that tile and are ignored.
-    const long long stride = (long long)waves_per_block * kTile;
-    const long long last = t + ((tf - 1 - t) / waves_per_block) * waves_per_block;   // this wave's last tile
-    int4 rc[kCustDepth];
+    // A tile is four loads, each of them contiguous over the wave: lane l takes orders 2l, 2l + 1 of the
+    // tile's first half and of its second half (ids 8 bytes, totals 16 bytes at a time).  With one lane's four
+    // orders side by side instead, a 16-byte load of totals covers half of every 64-byte piece it touches and
+    // the vector cache asks L2 for every piece twice.
+    // (tile numbers fit 32 bits: at most 2^31 orders; kept in scalar registers, the wave's number being one)
+    const int W = waves_per_block;
+    int t = (int)t0 + wave;
+    const int last = t + (((int)tf - 1 - t) / W) * W;         // this wave's last tile
+    int2 rc0[kCustDepth], rc1[kCustDepth];
     longlong2 ra[kCustDepth], rb[kCustDepth];
-    uint32_t rs[kCustDepth];                              // four state bytes per lane (lifecycle)
+    uint32_t rs[kCustDepth];                                  // four state bytes per lane (lifecycle)
     const bool stated = kLife && a.order_state != nullptr;
+    auto request = [&](int tile, int d) {
+      const size_t e = (size_t)(tile < last ? tile : last) * kTile + (size_t)lane * 2;
+      rc0[d] = *reinterpret_cast<const int2*>(a.order_customer + e);
+      rc1[d] = *reinterpret_cast<const int2*>(a.order_customer + e + kTile / 2);
+      ra[d] = *reinterpret_cast<const longlong2*>(a.order_total + e);
+      rb[d] = *reinterpret_cast<const longlong2*>(a.order_total + e + kTile / 2);
+      if (stated)
+        rs[d] = (uint32_t)*reinterpret_cast<const unsigned short*>(a.order_state + e) |
+                ((uint32_t)*reinterpret_cast<const unsigned short*>(a.order_state + e + kTile / 2) << 16);
+      // (kept where it stands: the tiles are asked for in the order in which the loop takes them, and a tile's
+      // registers are read before they are asked for again.  Moved up by the scheduler, old and new contents
+      // would be alive together in different registers and the end of the loop would move every set back into
+      // place, waiting for every load in flight; asked for out of order, the first tile taken may be the last
+      // one asked for, with the same wait at the top of the loop.)
+      __builtin_amdgcn_sched_barrier(0);
+    };
 #pragma unroll
-    for (int d = 0; d < kCustDepth; ++d) {
-      long long tt = t + (long long)d * waves_per_block;
-      if (tt > last) tt = last;
-      rc[d] = *reinterpret_cast<const int4*>(a.order_customer + tt * kTile + lane * 4);
-      ra[d] = *reinterpret_cast<const longlong2*>(a.order_total + tt * kTile + lane * 4);
-      rb[d] = *reinterpret_cast<const longlong2*>(a.order_total + tt * kTile + lane * 4 + 2);
-      rs[d] = stated ? *reinterpret_cast<const uint32_t*>(a.order_state + tt * kTile + lane * 4) : 0x01010101u;
-    }
-    for (; t <= last; t += (long long)kCustDepth * waves_per_block) {
+    for (int d = 0; d < kCustDepth; ++d) { rs[d] = 0x01010101u; request(t + d * W, d); }
+    for (; t <= last; t += kCustDepth * W) {
 #pragma unroll
       for (int d = 0; d < kCustDepth; ++d) {
-        const long long tc = t + (long long)d * waves_per_block;
-        const int4 c4 = rc[d];
-        const longlong2 ta = ra[d], tb = rb[d];
-        const uint32_t s4 = rs[d];
-        long long tn = tc + (long long)kCustDepth * waves_per_block;
-        if (tn > last) tn = last;
-        rc[d] = *reinterpret_cast<const int4*>(a.order_customer + tn * kTile + lane * 4);
-        ra[d] = *reinterpret_cast<const longlong2*>(a.order_total + tn * kTile + lane * 4);
-        rb[d] = *reinterpret_cast<const longlong2*>(a.order_total + tn * kTile + lane * 4 + 2);
-        if (stated) rs[d] = *reinterpret_cast<const uint32_t*>(a.order_state + tn * kTile + lane * 4);
+        const int tc = t + d * W;
         if (tc <= last) {
-          const int cs[4] = {c4.x, c4.y, c4.z, c4.w};
-          long long tv[4] = {ta.x, ta.y, tb.x, tb.y};
+          const int cs[4] = {rc0[d].x, rc0[d].y, rc1[d].x, rc1[d].y};
+          long long tv[4] = {ra[d].x, ra[d].y, rb[d].x, rb[d].y};
           if (kLife) {
+            const uint32_t s4 = rs[d];
 #pragma unroll
             for (int i = 0; i < 4; ++i) tv[i] = ((s4 >> (8 * i)) & 1u) ? tv[i] : 0ll;
           }
-          customers_tile<kLdsTables>(a, s_tab, s_dummy, lo, len, cs, tv, lane, st);
+          customers_tile<kLdsTables>(a, s_tab, s_scratch, lo, len, check_ids, cs, tv, st);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        request(tc + kCustDepth * W, d);
       }
     }
-    (void)stride;
   }
   if (wave == 0 && n_full < a.n_tiles && t0 <= n_full && n_full < t1) {
     // the last, partial tile of the order columns (it belongs to exactly one stream): orders past
@@ -1259,7 +1278,7 @@ __device__ __forceinline__ void customers_block(const CustArgs& a, unsigned char
       tv[i] = in ? a.order_total[o0 + i] : 0;
       if (kLife && a.order_state && in && !(a.order_state[o0 + i] & 1)) tv[i] = 0;
     }
-    customers_tile<kLdsTables>(a, s_tab, s_dummy, lo, len, cs, tv, lane, st);
+    customers_tile<kLdsTables>(a, s_tab, s_scratch, lo, len, check_ids, cs, tv, st);
   }
   if (st && r == 0) atomicOr(a.status, st);
   if (kLdsTables) {
