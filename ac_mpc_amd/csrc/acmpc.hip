@@ -307,7 +307,11 @@ int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p, bool line_pr
   int max_blocks = (ctx->k1_cus > 0 ? std::min(ctx->k1_cus, ctx->n_cu) : ctx->n_cu) * bpc;
   max_blocks = std::min(max_blocks, kMaxWavesTotal / p->waves_per_block);
   p->n_tiles = (n_lines + p->tile_lines - 1) / p->tile_lines;
-  const int64_t max_waves = (int64_t)max_blocks * p->waves_per_block;
+  // Small inputs: at least eight tiles per wave while that leaves a thousand waves.  Every wave costs the record
+  // block two records, and a launch that short is paid for in latency, not in bytes (1 M lines: 0.044 -> 0.039 ms
+  // per call, 4 M: 0.054 -> 0.050 ms; from 16 M lines on the cap below is what binds).
+  const int64_t max_waves = std::min<int64_t>((int64_t)max_blocks * p->waves_per_block,
+                                              std::max<int64_t>(1024, p->n_tiles / 8));
   p->tiles_per_wave = std::max<int64_t>(1, (p->n_tiles + max_waves - 1) / max_waves);
   if (ctx->k1_tpw > 0) p->tiles_per_wave = std::max<int64_t>(p->tiles_per_wave, ctx->k1_tpw);   // developer switch
   p->n_active_waves = (int)((p->n_tiles + p->tiles_per_wave - 1) / p->tiles_per_wave);
