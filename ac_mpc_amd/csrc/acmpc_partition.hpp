@@ -396,19 +396,22 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_b(PartArgs a) {
   const long long n_rec = (long long)a.bucket_off[kPartMaxBuckets];
   const long long n_rounds = (n_rec + kPartRoundB - 1) / kPartRoundB;
 
-  // thread t holds records 4t .. 4t+3 of each half of the round (two 16-byte loads per half)
+  // A round is four quarters of 2048 records; thread t holds records 2t, 2t + 1 of each quarter: one 16-byte load
+  // per quarter, contiguous over the workgroup.  (Four consecutive records per thread would make every load cover
+  // half of each 64-byte piece it touches, and the vector cache would ask for every piece twice.)
+  constexpr int kQuarter = kPartRoundB / 4;
   auto load_round = [&](long long r, unsigned long long (&rec)[8]) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const long long e0 = r * kPartRoundB + (long long)h * kPartRound + (long long)tid * 4;
-      if (e0 + 4 <= n_rec) {
-        long long q[4];
-        load_prices<4>(reinterpret_cast<const long long*>(a.rec_a + e0), q);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rec[4 * h + i] = (unsigned long long)q[i];
+    for (int h = 0; h < 4; ++h) {
+      const long long e0 = r * kPartRoundB + (long long)h * kQuarter + (long long)tid * 2;
+      if (e0 + 2 <= n_rec) {
+        long long q[2];
+        load_prices<2>(reinterpret_cast<const long long*>(a.rec_a + e0), q);
+        rec[2 * h] = (unsigned long long)q[0];
+        rec[2 * h + 1] = (unsigned long long)q[1];
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rec[4 * h + i] = e0 + i < n_rec ? a.rec_a[e0 + i] : 0ull;    // (past the end: dropped below)
+        for (int i = 0; i < 2; ++i) rec[2 * h + i] = e0 + i < n_rec ? a.rec_a[e0 + i] : 0ull;    // (past the end: dropped below)
       }
     }
   };
@@ -425,7 +428,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_b(PartArgs a) {
     // every bucket number is a record's; places past the last record go to the drop bin
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const long long e = r * kPartRoundB + (long long)(i >> 2) * kPartRound + (long long)tid * 4 + (i & 3);
+      const long long e = r * kPartRoundB + (long long)(i >> 1) * kQuarter + (long long)tid * 2 + (i & 1);
       bin[i] = e < n_rec ? (uint32_t)(rec[i] >> (kPartValBits + kPartShift)) : (uint32_t)kPartMaxBuckets;
     }
     part_rank_many<8>(s_cnt, bin, lane, pos);
