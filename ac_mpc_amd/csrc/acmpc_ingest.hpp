@@ -557,20 +557,24 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
   uint32_t bad = 0;                                        // malformed rows met by this thread (a chunk holds < 2^13 rows)
   const int o = tid * kIngPerThread;                       // this thread's slice inside a chunk
 
-  // text of a chunk on its way to LDS: the thread's own 48 bytes, a piece of the look-ahead (the first
-  // kIngLook / 16 threads) and the byte in front of the chunk (thread 0)
-  uint4 rt[kIngPerThread / 16], rl;
+  // text of a chunk on its way to LDS: three 16-byte pieces per thread, each load contiguous over the workgroup
+  // (piece j of thread t is bytes [j * 4096 + 16 t, + 16) of the chunk; the thread's OWN 48 bytes are read back
+  // from LDS once the chunk is staged: loaded directly they are 48 bytes apart from lane to lane, and every one
+  // of the three loads then touches every 64-byte piece of the wave's 3 KB), a piece of the look-ahead (the
+  // first kIngLook / 16 threads) and the byte in front of the chunk (thread 0)
+  constexpr int kIngPieces = kIngPerThread / 16, kIngPieceStride = kIngThreads * 16;
+  uint4 rt[kIngPieces], rl;
   uint32_t rprev = (uint32_t)'\n';
   auto request_text = [&](int64_t c) {
     const int64_t cbase = c * kIngChunk;
     if (cbase + kIngChunk + kIngLook <= a.n_bytes) {       // uniform: every chunk but the last one or two
-      const uint4* src = reinterpret_cast<const uint4*>(a.text + cbase + o);
 #pragma unroll
-      for (int j = 0; j < kIngPerThread / 16; ++j) rt[j] = src[j];
+      for (int j = 0; j < kIngPieces; ++j)
+        rt[j] = *reinterpret_cast<const uint4*>(a.text + cbase + j * kIngPieceStride + 16 * tid);
       if (tid < kIngLook / 16) rl = *reinterpret_cast<const uint4*>(a.text + cbase + kIngChunk + 16 * tid);
     } else {
 #pragma unroll
-      for (int j = 0; j < kIngPerThread / 16; ++j) rt[j] = ing_load_piece(a.text, cbase + o + 16 * j, a.n_bytes);
+      for (int j = 0; j < kIngPieces; ++j) rt[j] = ing_load_piece(a.text, cbase + j * kIngPieceStride + 16 * tid, a.n_bytes);
       if (tid < kIngLook / 16) rl = ing_load_piece(a.text, cbase + kIngChunk + 16 * tid, a.n_bytes);
     }
     if (tid == 0) rprev = c > 0 ? (uint32_t)a.text[cbase - 1] : (uint32_t)'\n';
@@ -600,21 +604,25 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
 
   for (;;) {
     __syncthreads();                                       // the rows parsed last round have been read out of s_text[buf]
-    unsigned long long nl = 0;
     if (c_next >= 0) {                                     // uniform
       unsigned char* t = s_text[buf] + kIngFront;
-      uint32_t w[kIngWords];
 #pragma unroll
-      for (int j = 0; j < kIngPerThread / 16; ++j) {
-        *reinterpret_cast<uint4*>(t + o + 16 * j) = rt[j];
-        w[4 * j] = rt[j].x; w[4 * j + 1] = rt[j].y; w[4 * j + 2] = rt[j].z; w[4 * j + 3] = rt[j].w;
-      }
+      for (int j = 0; j < kIngPieces; ++j) *reinterpret_cast<uint4*>(t + j * kIngPieceStride + 16 * tid) = rt[j];
       if (tid < kIngLook / 16) *reinterpret_cast<uint4*>(t + kIngChunk + 16 * tid) = rl;
       if (tid == 0) { t[-1] = (unsigned char)rprev; s_tk[par] = tk_pending; }
-      nl = ing_newline_mask(w);
     }
     __syncthreads();
     if (c_next >= 0) {
+      unsigned long long nl;
+      {
+        uint32_t w[kIngWords];
+#pragma unroll
+        for (int j = 0; j < kIngPieces; ++j) {
+          const uint4 x = *reinterpret_cast<const uint4*>(s_text[buf] + kIngFront + o + 16 * j);
+          w[4 * j] = x.x; w[4 * j + 1] = x.y; w[4 * j + 2] = x.z; w[4 * j + 3] = x.w;
+        }
+        nl = ing_newline_mask(w);
+      }
       // line starts of the slice (the byte in front is a newline, or the text starts here), then the data
       // rows among them by their first one or two bytes; a statement line hands out the position of its '('
       const unsigned char* t = s_text[buf] + kIngFront;
