@@ -152,3 +152,22 @@ def test_device_totals_at_bench_size_properties(motor, oracle, em, style):
     assert bytes(text[:len(head)].cpu().numpy()) == head
     tail = oracle.emit_totals(tot[-5000:].cpu().numpy(), 5 + m - 5000, style)
     assert bytes(text[n - len(tail):n].cpu().numpy()) == tail
+
+
+@pytest.mark.parametrize("style", [0, 1, 2])
+def test_device_totals_column_that_is_only_8_byte_aligned(motor, oracle, em, style):
+    """The totals may start anywhere an int64 may: a view one element into a tensor (the CSV kernel reads a
+    thread's four values 16 bytes at a time only when the column allows it)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    vals = ec.random_values(10_007, 77)
+    whole = torch.zeros(len(vals) + 1, dtype=torch.int64, device=dev)
+    col = whole[1:]
+    col.copy_(torch.from_numpy(vals))
+    assert col.data_ptr() % 16 == 8
+    text = torch.empty(len(vals) * 96, dtype=torch.uint8, device=dev)
+    nb = torch.zeros(1, dtype=torch.int64, device=dev)
+    em.totales_device(motor, col, -3, style, text, nb)
+    assert motor.estado() == 0
+    n = int(nb.item())
+    assert bytes(text[:n].cpu().numpy()) == oracle.emit_totals(vals, -3, style)
