@@ -483,6 +483,8 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
   // fixed_ws: null = the context's own workspace, grown with hipMalloc as needed; otherwise the device
   // address of the fixed scratch array, and this call allocates nothing (and refuses what does not fit).
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_aggregate_device: null context");
+  // a lifecycle argument without any column is no lifecycle argument (and takes the plain path's three launches)
+  if (life && !life->line_price_cents && !life->order_state && !life->order_descuento) life = nullptr;
   const int64_t* d_line_price = life ? life->line_price_cents : nullptr;
   const uint8_t* d_state = life ? life->order_state : nullptr;
   const int32_t* d_desc = life ? life->order_descuento : nullptr;
