@@ -40,8 +40,9 @@ CENT = Decimal("0.01")
 
 
 def php_float_to_string(x: float) -> str:
-    """PHP 7 ``(string)$float`` with ini ``precision=14`` (``%.14G``)."""
-    if x == int(x) and abs(x) < 1e15:
+    """PHP 7 ``(string)$float`` with ini ``precision=14`` (``%.14G``): fixed notation while the value
+    has at most 14 digits before the point, exponent notation from 1e14 on (``1.0E+14``)."""
+    if x == int(x) and abs(x) < 1e14:
         return str(int(x))
     s = "%.14G" % x
     if "E" in s:

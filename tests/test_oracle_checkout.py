@@ -61,6 +61,13 @@ def test_php_float_string_and_number_format():
     assert co.php_float_to_string(1234.5) == "1234.5"
     assert co.php_float_to_string(0.1 + 0.2) == "0.3"
     assert co.php_float_to_string(1234567.89) == "1234567.89"
+    # precision=14: fourteen digits print in full, the fifteenth switches to exponent notation
+    assert co.php_float_to_string(99999999999999.0) == "99999999999999"
+    assert co.php_float_to_string(1e14) == "1.0E+14"
+    assert co.php_float_to_string(123456789012345.0) == "1.2345678901234E+14"
+    assert co.php_float_to_string(-1e14) == "-1.0E+14"
+    assert co.php_float_to_string(99999999999999.5) == "1.0E+14"
+    assert co.php_float_to_string(0.00001) == "1.0E-5"
     assert co.php_number_format_2(2200.0) == "2,200.00"
     assert co.php_number_format_2(0) == "0.00"
     assert co.php_number_format_2(1234567.891) == "1,234,567.89"
@@ -86,6 +93,33 @@ def test_double_path_equals_integer_cents_inside_the_bound():
 
 def test_bound_rejects_huge_totals():
     assert not co.equivalence_bound_ok([Decimal("999999999999.99")] * 2)
+
+
+def test_where_the_double_path_and_the_integer_cent_path_part():
+    """A checkout whose total crosses 10^12 currency units.  Fourteen significant digits no longer reach the
+    cent there, so what process/confirmcompra.php:24 hands to MariaDB loses the cents and, from 10^14 on, is in
+    exponent notation and loses whole units too.  Documented, not asserted equal: the engine's integer-cent
+    totals are exact, the reference's double path is not, which is why equivalence_bound_ok() stops at 10^12."""
+    store = co.Store()
+    store.producto["X"] = Decimal("600000000000.37")          # a DECIMAL(30,2) column holds it (store.sql:113)
+    store.cliente[("u", co.md5("p"))] = 1
+    chk = co.Checkout(store)
+    ses = co.Session()
+    chk.carrito(ses, "X")
+    chk.carrito(ses, "X")                                     # 1,200,000,000,000.74
+    assert not co.equivalence_bound_ok([store.producto["X"]] * 2)
+    assert co.php_float_to_string(float(ses.sumaTotal)) == "1200000000000.7"      # 14 digits: the cent is gone
+    assert chk.confirmcompra(ses, "u", co.md5("p")).startswith("El pedido")
+    assert store.venta[0]["TotalPagar"] == Decimal("1200000000000.70")
+    assert co.cents_total(store, ["X", "X"]) == 120000000000074                   # the integer-cent path keeps it
+    # two orders of magnitude further the reference's text is in exponent notation and rounds to units of ten
+    store.producto["Y"] = Decimal("61728394506172.50")
+    ses = co.Session()
+    chk.carrito(ses, "Y")
+    chk.carrito(ses, "Y")                                     # 123,456,789,012,345.00
+    assert co.php_float_to_string(float(ses.sumaTotal)) == "1.2345678901234E+14"
+    assert co.mariadb_decimal_30_2("1.2345678901234E+14") == Decimal("123456789012340.00")
+    assert co.cents_total(store, ["Y", "Y"]) == 12345678901234500
 
 
 def test_aggregate_py_matches_sqlite_group_by():
