@@ -21,7 +21,7 @@ EXPORTS = (
     "acmpc_emit_totals_device", "acmpc_emit_stock_device", "acmpc_emit_totals", "acmpc_emit_stock",
     "acmpc_host_alloc", "acmpc_host_free", "acmpc_aggregate_device_noalloc",
     "acmpc_comm_id", "acmpc_comm_init_rank", "acmpc_comm_init_all", "acmpc_comm_destroy", "acmpc_merge_device",
-    "acmpc_merge_group_device", "acmpc_aggregate_sharded",
+    "acmpc_merge_group_device", "acmpc_aggregate_sharded", "acmpc_shard_plan", "acmpc_shard_partition",
 )
 
 OK, E_INVALID, E_HIP, E_ALIGN, E_DATA, E_STATE, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
@@ -112,6 +112,10 @@ def load() -> C.CDLL:
     lib.acmpc_merge_group_device.restype = C.c_int
     lib.acmpc_aggregate_sharded.argtypes = [vp, vp, C.c_int, vp, vp, vp, i64, vp, i64, i32, i32, vp, vp, vp]
     lib.acmpc_aggregate_sharded.restype = C.c_int
+    lib.acmpc_shard_plan.argtypes = [vp, i64, i64, i32, C.c_int, C.c_int, vp, vp]
+    lib.acmpc_shard_plan.restype = C.c_int
+    lib.acmpc_shard_partition.argtypes = [vp, vp, vp, i64, i64, i32, C.c_int, vp, vp, vp, vp]
+    lib.acmpc_shard_partition.restype = C.c_int
     lib.acmpc_status.argtypes = [vp, vp, u32p]
     lib.acmpc_status.restype = C.c_int
     lib.acmpc_set_option.argtypes = [vp, C.c_int, i64]

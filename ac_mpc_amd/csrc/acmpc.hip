@@ -12,7 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 #include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -57,7 +60,10 @@ static_assert(kNaOffCustSlab % 256 == 0 && kNaOffProdCarry % 256 == 0 && kNaOffC
               kNaOffRecId % 256 == 0 && kNaRecBytes % 256 == 0, "scratch regions stay 256-byte aligned");
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 constexpr int kMaxDevices = 64;
-unsigned char* g_scratch_ptr[kMaxDevices] = {};           // device address of `scratch` on every device seen
+// device address of `scratch` on every device seen.  Contexts may be created from different threads: the
+// address of a device is looked up under the lock and published with an atomic store.
+std::atomic<unsigned char*> g_scratch_ptr[kMaxDevices];
+std::mutex g_scratch_lock;
 
 template <typename T>
 struct DevBuf {
@@ -193,6 +199,8 @@ int guarded(acmpc_ctx* ctx, const char* who, F&& body) {
     return body();
   } catch (const std::bad_alloc&) {
     return fail(ctx, ACMPC_E_NOMEM, "%s: out of host memory", who);
+  } catch (const std::system_error& e) {
+    return fail(ctx, ACMPC_E_NOMEM, "%s: %s", who, e.what());     // (a thread or lock the system would not give)
   } catch (...) {
     return fail(ctx, ACMPC_E_INVALID, "%s: unexpected exception", who);
   }
@@ -914,17 +922,17 @@ ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
   ctx->k2_cus = env_int("ACMPC_K2_CUS", 0);
   if (ctx->k2_threads != 256 && ctx->k2_threads != 512 && ctx->k2_threads != 1024) ctx->k2_threads = 1024;
   ctx->force_global_tables = env_int("ACMPC_FORCE_GLOBAL_TABLES", 0);
-  if (device < kMaxDevices && !g_scratch_ptr[device]) {
+  if (device < kMaxDevices && !g_scratch_ptr[device].load(std::memory_order_acquire)) {
     // `device` is current here.  The array's name is not a device address: this call returns the one the
-    // kernels can use on this device.
-    unsigned char* sp = nullptr;
-    const hipError_t es = hipGetSymbolAddress((void**)&sp, HIP_SYMBOL(scratch));
-    if (es != hipSuccess || !sp) {
-      fail(nullptr, ACMPC_E_HIP, "acmpc_init: hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(es));
-      delete ctx;
-      return ACMPC_E_HIP;
+    // kernels can use on this device.  A failure only matters to the allocation-free entry point, which then
+    // finds no address and says so; every other call works without the array.
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (!g_scratch_ptr[device].load(std::memory_order_relaxed)) {
+      unsigned char* sp = nullptr;
+      const hipError_t es = hipGetSymbolAddress((void**)&sp, HIP_SYMBOL(scratch));
+      if (es == hipSuccess && sp) g_scratch_ptr[device].store(sp, std::memory_order_release);
+      else (void)hipGetLastError();
     }
-    g_scratch_ptr[device] = sp;
   }
   hipError_t e = hipMalloc((void**)&ctx->d_status, sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemset(ctx->d_status, 0, sizeof(uint32_t));
@@ -1003,7 +1011,7 @@ ACMPC_API int acmpc_aggregate_device_noalloc(acmpc_ctx* ctx, const int32_t* d_or
                                              int64_t* d_out_order_total_cents, int64_t* d_out_product_qty,
                                              int64_t* d_out_customer_total_cents, void* hip_stream) {
   if (!ctx) return fail(nullptr, ACMPC_E_INVALID, "acmpc_aggregate_device_noalloc: null context");
-  unsigned char* ws = ctx->device < kMaxDevices ? g_scratch_ptr[ctx->device] : nullptr;   // set by acmpc_init
+  unsigned char* ws = ctx->device < kMaxDevices ? g_scratch_ptr[ctx->device].load(std::memory_order_acquire) : nullptr;   // set by acmpc_init
   if (!ws) return fail(ctx, ACMPC_E_STATE, "acmpc_aggregate_device_noalloc: no scratch address for device %d", ctx->device);
   return aggregate_device_impl(ctx, d_order_id, d_product_idx, d_qty, n_lines, d_order_customer, n_orders,
                                order_id_base, n_customers, d_out_order_total_cents, d_out_product_qty,
@@ -1070,15 +1078,19 @@ int host_copies(acmpc_ctx* ctx, const std::vector<HostCopy>& jobs, hipStream_t s
       pieces.push_back({static_cast<char*>(j.dst) + off, static_cast<const char*>(j.src) + off, std::min(piece, j.bytes - off), j.kind});
   hipError_t errs[kThreads];
   std::thread threads[kThreads];
-  for (int t = 0; t < kThreads; ++t)
-    threads[t] = std::thread([&, t] {
-      hipError_t e = hipSetDevice(ctx->device);
-      for (size_t k = (size_t)t; k < pieces.size() && e == hipSuccess; k += kThreads)
-        e = hipMemcpyAsync(pieces[k].dst, pieces[k].src, pieces[k].bytes, pieces[k].kind, ctx->copy_streams[t]);
-      const hipError_t w = hipStreamSynchronize(ctx->copy_streams[t]);
-      errs[t] = e != hipSuccess ? e : w;
-    });
-  for (std::thread& t : threads) t.join();
+  auto share = [&](int t) {
+    hipError_t e = hipSetDevice(ctx->device);
+    for (size_t k = (size_t)t; k < pieces.size() && e == hipSuccess; k += kThreads)
+      e = hipMemcpyAsync(pieces[k].dst, pieces[k].src, pieces[k].bytes, pieces[k].kind, ctx->copy_streams[t]);
+    const hipError_t w = hipStreamSynchronize(ctx->copy_streams[t]);
+    errs[t] = e != hipSuccess ? e : w;
+  };
+  for (int t = 0; t < kThreads; ++t) {
+    // a thread the system will not start (process or thread limit): its share is copied from this thread
+    try { threads[t] = std::thread(share, t); } catch (const std::system_error&) { share(t); }
+  }
+  for (std::thread& t : threads)
+    if (t.joinable()) t.join();
   for (hipError_t e : errs) HIPCHK(ctx, e);
   return ACMPC_OK;
 }
@@ -1107,6 +1119,7 @@ ACMPC_API int acmpc_aggregate_lifecycle(acmpc_ctx* ctx, const int32_t* order_id,
   if ((n_lines > 0 && (!order_id || !product_idx || !qty)) || (n_orders > 0 && (!order_customer || !out_order_total_cents)) ||
       !out_product_qty || !out_customer_total_cents)
     return fail(ctx, ACMPC_E_INVALID, "null host pointer");
+  return guarded(ctx, "acmpc_aggregate", [&]() -> int {
   ENTER_DEVICE(ctx);
   const int32_t P = ctx->n_products;
   int rc;
@@ -1158,6 +1171,7 @@ ACMPC_API int acmpc_aggregate_lifecycle(acmpc_ctx* ctx, const int32_t* order_id,
   if ((rc = host_copies(ctx, down, st))) return rc;
   uint32_t flags = 0;
   return acmpc_status(ctx, st, &flags);
+  });
 }
 
 ACMPC_API int acmpc_set_option(acmpc_ctx* ctx, int option, int64_t value) {
@@ -1490,6 +1504,7 @@ ACMPC_API int acmpc_ingest_detalle(acmpc_ctx* ctx, const char* text, int64_t n_b
   if (n_bytes < 0 || capacity_rows < 0 || !n_rows || (n_bytes > 0 && !text))
     return fail(ctx, ACMPC_E_INVALID, "acmpc_ingest_detalle: bad argument");
   if (capacity_rows > 0 && (!order_id || !product_idx || !qty)) return fail(ctx, ACMPC_E_INVALID, "null column pointer");
+  return guarded(ctx, "acmpc_ingest_detalle", [&]() -> int {
   ENTER_DEVICE(ctx);
   int rc;
   if ((rc = ensure(ctx, ctx->s_text, (size_t)n_bytes + 16))) return rc;
@@ -1515,6 +1530,7 @@ ACMPC_API int acmpc_ingest_detalle(acmpc_ctx* ctx, const char* text, int64_t n_b
   if (got > 0) HIPCHK(ctx, hipStreamSynchronize(st));      // (small results are only queued by host_copies)
   uint32_t flags = 0;
   return acmpc_status(ctx, st, &flags);
+  });
 }
 
 // ---- text emit ---------------------------------------------------------------------------
@@ -1571,6 +1587,7 @@ int emit_host_impl(acmpc_ctx* ctx, const char* who, int kind, const int64_t* val
                    int style, char* text, int64_t capacity, int64_t* n_bytes) {
   if (!n_bytes || n_rows < 0 || capacity < 0 || (n_rows > 0 && !value) || (capacity > 0 && !text))
     return fail(ctx, ACMPC_E_INVALID, "%s: bad argument", who);
+  return guarded(ctx, who, [&]() -> int {
   ENTER_DEVICE(ctx);
   int rc;
   if ((rc = ensure(ctx, ctx->s_emit_value, (size_t)n_rows))) return rc;
@@ -1598,6 +1615,7 @@ int emit_host_impl(acmpc_ctx* ctx, const char* who, int kind, const int64_t* val
   }
   uint32_t flags = 0;
   return acmpc_status(ctx, st, &flags);
+  });
 }
 
 }  // namespace
@@ -1777,6 +1795,95 @@ ACMPC_API int acmpc_merge_group_device(acmpc_ctx* const* ctxs, acmpc_comm* const
   return ACMPC_OK;
 }
 
+namespace {
+
+// Order-index cuts of the shards: shard g owns [o_cut[g], o_cut[g + 1]).
+void shard_order_cuts(int64_t n_orders, int n_devices, int64_t* o_cut) {
+  for (int g = 0; g <= n_devices; ++g) o_cut[g] = (int64_t)(((__int128)n_orders * g) / n_devices);
+}
+
+// The shard that owns the line with this order id.  An id below the base goes to the first shard that has
+// orders and an id at or past base + M to the last one: the device pass of that shard reports it.
+inline int shard_of_id(int32_t id, int32_t base, int64_t n_orders, int n_devices, const int64_t* o_cut, int first_owner) {
+  const int64_t idx = (int64_t)id - (int64_t)base;
+  if (idx < 0) return first_owner;
+  if (idx >= n_orders) return n_devices - 1;
+  return (int)(std::upper_bound(o_cut, o_cut + n_devices + 1, idx) - o_cut) - 1;
+}
+
+int shard_plan_check(const int32_t* order_id, int64_t n_lines, int64_t n_orders, int n_devices, const void* o_cut,
+                     const void* l_cut) {
+  if (n_devices <= 0 || n_devices > kMaxDevices) return fail(nullptr, ACMPC_E_INVALID, "shard plan: %d devices (1 to %d)", n_devices, kMaxDevices);
+  if (n_lines < 0 || n_orders < 0 || n_orders > 0x7fffffffll) return fail(nullptr, ACMPC_E_INVALID, "shard plan: bad size");
+  if (n_lines > 0 && !order_id) return fail(nullptr, ACMPC_E_INVALID, "shard plan: null order_id");
+  if (n_lines > 0 && n_orders == 0) return fail(nullptr, ACMPC_E_INVALID, "n_lines > 0 with n_orders == 0");
+  if (!o_cut || !l_cut) return fail(nullptr, ACMPC_E_INVALID, "shard plan: null output");
+  return ACMPC_OK;
+}
+
+}  // namespace
+
+ACMPC_API int acmpc_shard_plan(const int32_t* order_id, int64_t n_lines, int64_t n_orders, int32_t order_id_base,
+                               int n_devices, int line_order, int64_t* o_cut, int64_t* l_cut) {
+  int rc = shard_plan_check(order_id, n_lines, n_orders, n_devices, o_cut, l_cut);
+  if (rc) return rc;
+  if (line_order != ACMPC_ORDER_GROUPED && line_order != ACMPC_ORDER_ANY && line_order != ACMPC_ORDER_AUTO)
+    return fail(nullptr, ACMPC_E_INVALID, "shard plan: unknown line order %d", line_order);
+  shard_order_cuts(n_orders, n_devices, o_cut);
+  int first_owner = 0;                                   // the first shard that owns any order
+  while (first_owner < n_devices - 1 && o_cut[first_owner + 1] == o_cut[first_owner]) ++first_owner;
+  const bool sorted = line_order == ACMPC_ORDER_GROUPED || std::is_sorted(order_id, order_id + n_lines);
+  if (sorted) {
+    // Grouped rows: the cut in front of shard g is the first line whose id reaches the shard's first order.
+    // The cuts are forced to ascend, so that every line lands in exactly one shard whatever the column holds:
+    // on a column that is not sorted after all, a descent either lies inside a shard or leaves one of its two
+    // lines outside its shard's id range, and the device pass reports either.
+    l_cut[0] = 0;
+    for (int g = 1; g < n_devices; ++g) {
+      const int64_t first_id = (int64_t)order_id_base + o_cut[g];
+      const int64_t at = g <= first_owner ? 0     // ids below the base stay with the first shard that has orders
+                                          : std::lower_bound(order_id, order_id + n_lines, first_id,
+                                                             [](int32_t a, int64_t b) { return (int64_t)a < b; }) - order_id;
+      l_cut[g] = std::max(l_cut[g - 1], at);
+    }
+    l_cut[n_devices] = n_lines;
+    return ACMPC_OK;
+  }
+  // Rows in any order: shard g gets the lines of its orders, wherever they stand; l_cut are their places after
+  // a stable partition of the rows by shard (acmpc_shard_partition).
+  int64_t count[kMaxDevices] = {};
+  for (int64_t l = 0; l < n_lines; ++l) ++count[shard_of_id(order_id[l], order_id_base, n_orders, n_devices, o_cut, first_owner)];
+  l_cut[0] = 0;
+  for (int g = 0; g < n_devices; ++g) l_cut[g + 1] = l_cut[g] + count[g];
+  return ACMPC_OK;
+}
+
+ACMPC_API int acmpc_shard_partition(const int32_t* order_id, const int32_t* product_idx, const int32_t* qty,
+                                    int64_t n_lines, int64_t n_orders, int32_t order_id_base, int n_devices,
+                                    int32_t* out_order_id, int32_t* out_product_idx, int32_t* out_qty, int64_t* l_cut) {
+  int64_t o_cut[kMaxDevices + 1];
+  int rc = shard_plan_check(order_id, n_lines, n_orders, n_devices, o_cut, l_cut);
+  if (rc) return rc;
+  if (n_lines > 0 && (!product_idx || !qty || !out_order_id || !out_product_idx || !out_qty))
+    return fail(nullptr, ACMPC_E_INVALID, "acmpc_shard_partition: null column");
+  if ((rc = acmpc_shard_plan(order_id, n_lines, n_orders, order_id_base, n_devices, ACMPC_ORDER_ANY, o_cut, l_cut))) return rc;
+  if (std::is_sorted(order_id, order_id + n_lines)) {    // (the plan then made contiguous cuts: the rows stay where they are)
+    std::copy(order_id, order_id + n_lines, out_order_id);
+    std::copy(product_idx, product_idx + n_lines, out_product_idx);
+    std::copy(qty, qty + n_lines, out_qty);
+    return ACMPC_OK;
+  }
+  int first_owner = 0;
+  while (first_owner < n_devices - 1 && o_cut[first_owner + 1] == o_cut[first_owner]) ++first_owner;
+  int64_t at[kMaxDevices];
+  for (int g = 0; g < n_devices; ++g) at[g] = l_cut[g];
+  for (int64_t l = 0; l < n_lines; ++l) {
+    const int64_t k = at[shard_of_id(order_id[l], order_id_base, n_orders, n_devices, o_cut, first_owner)]++;
+    out_order_id[k] = order_id[l]; out_product_idx[k] = product_idx[l]; out_qty[k] = qty[l];
+  }
+  return ACMPC_OK;
+}
+
 ACMPC_API int acmpc_aggregate_sharded(acmpc_ctx* const* ctxs, acmpc_comm* const* comms, int n_devices,
                                       const int32_t* order_id, const int32_t* product_idx, const int32_t* qty,
                                       int64_t n_lines, const int32_t* order_customer, int64_t n_orders,
@@ -1790,10 +1897,13 @@ ACMPC_API int acmpc_aggregate_sharded(acmpc_ctx* const* ctxs, acmpc_comm* const*
   acmpc_ctx* ctx0 = ctxs[0];
   const int32_t P = ctx0->n_products;
   if (P <= 0) return fail(ctx0, ACMPC_E_STATE, "acmpc_set_products has not been called");
-  for (int g = 1; g < n_devices; ++g)
+  for (int g = 1; g < n_devices; ++g) {
     if (ctxs[g]->n_products != P)
       return fail(ctx0, ACMPC_E_STATE, "acmpc_aggregate_sharded: context %d holds %d products, context 0 holds %d", g,
                   ctxs[g]->n_products, P);
+    if (ctxs[g]->line_order != ctx0->line_order)
+      return fail(ctx0, ACMPC_E_STATE, "acmpc_aggregate_sharded: context %d has another ACMPC_OPT_LINE_ORDER than context 0", g);
+  }
   if (n_lines < 0 || n_orders < 0 || n_customers <= 0) return fail(ctx0, ACMPC_E_INVALID, "negative size or n_customers <= 0");
   if (n_orders > 0x7fffffffll || n_lines > (1ll << 40) || n_customers > kMaxCustomers)
     return fail(ctx0, ACMPC_E_INVALID, "size beyond the limits (n_orders int32, n_lines 2^40, n_customers %d)", kMaxCustomers);
@@ -1801,29 +1911,40 @@ ACMPC_API int acmpc_aggregate_sharded(acmpc_ctx* const* ctxs, acmpc_comm* const*
       !out_product_qty || !out_customer_total_cents)
     return fail(ctx0, ACMPC_E_INVALID, "null host pointer");
   if (n_lines > 0 && n_orders == 0) return fail(ctx0, ACMPC_E_INVALID, "n_lines > 0 with n_orders == 0");
+  return guarded(ctx0, "acmpc_aggregate_sharded", [&]() -> int {
   const int64_t n_merged = (int64_t)P + n_customers;
   DeviceScope keep;                                    // the loop below moves the current device about
   HIPCHK(ctx0, keep.enter(ctx0->device));
-  // Shard g owns the order indices [floor(g*M/G), floor((g+1)*M/G)) and exactly their lines: the cut in
-  // the line columns is the first line whose id reaches the shard's first order (the ids ascend).
+  // The shards (acmpc_shard_plan).  Grouped rows are cut where they lie; rows in any order that are not sorted
+  // are first brought together shard by shard in host memory (a counting pass and a stable scatter), since a
+  // shard's lines then lie anywhere in the columns.
   int64_t o_cut[kMaxDevices + 1], l_cut[kMaxDevices + 1];
-  for (int g = 0; g <= n_devices; ++g) {
-    o_cut[g] = (int64_t)(((__int128)n_orders * g) / n_devices);
-    const int64_t first_id = (int64_t)order_id_base + o_cut[g];
-    l_cut[g] = g == n_devices ? n_lines
-                              : std::lower_bound(order_id, order_id + n_lines, first_id,
-                                                 [](int32_t a, int64_t b) { return (int64_t)a < b; }) - order_id;
+  int rc = acmpc_shard_plan(order_id, n_lines, n_orders, order_id_base, n_devices, ctx0->line_order, o_cut, l_cut);
+  if (rc) return fail(ctx0, rc, "%s", g_init_error);
+  std::vector<int32_t> moved;                            // the three partitioned columns, one after the other
+  const int32_t *src_id = order_id, *src_pr = product_idx, *src_q = qty;
+  if (ctx0->line_order != ACMPC_ORDER_GROUPED && n_devices > 1 && !std::is_sorted(order_id, order_id + n_lines)) {
+    moved.resize((size_t)n_lines * 3);
+    int32_t* m = moved.data();
+    if ((rc = acmpc_shard_partition(order_id, product_idx, qty, n_lines, n_orders, order_id_base, n_devices, m, m + n_lines,
+                                    m + 2 * n_lines, l_cut)))
+      return fail(ctx0, rc, "%s", g_init_error);
+    src_id = m; src_pr = m + n_lines; src_q = m + 2 * n_lines;
   }
-  l_cut[0] = 0;                                        // ids below the base stay with shard 0, which reports them
   // One host thread per device for the two phases that move host memory: a copy from or to pageable memory
   // holds its calling thread until the data has gone through the staging buffers, so issued from one thread the
-  // shards would cross their PCIe links one after the other.  (A thread sets its own current device.)
+  // shards would cross their PCIe links one after the other.  (A thread sets its own current device.)  A thread
+  // the system will not start has its shard served from the calling thread instead.
   std::vector<int> rcs((size_t)n_devices, ACMPC_OK);
   auto on_every_device = [&](auto&& body) {
     std::vector<std::thread> threads;
     threads.reserve((size_t)n_devices);
-    for (int g = 0; g < n_devices; ++g) threads.emplace_back([&, g] { rcs[(size_t)g] = body(g); });
+    for (int g = 0; g < n_devices; ++g) {
+      try { threads.emplace_back([&, g] { rcs[(size_t)g] = body(g); }); }
+      catch (const std::system_error&) { rcs[(size_t)g] = body(g); }
+    }
     for (std::thread& t : threads) t.join();
+    (void)hipSetDevice(ctx0->device);                  // (a shard served from this thread moved the current device)
     for (int g = 0; g < n_devices; ++g)
       if (rcs[(size_t)g] != ACMPC_OK) {
         if (ctxs[g] != ctx0) fail(ctx0, rcs[(size_t)g], "shard %d: %s", g, ctxs[g]->err);
@@ -1831,7 +1952,7 @@ ACMPC_API int acmpc_aggregate_sharded(acmpc_ctx* const* ctxs, acmpc_comm* const*
       }
     return (int)ACMPC_OK;
   };
-  int rc = on_every_device([&](int g) -> int {
+  rc = on_every_device([&](int g) -> int {
     acmpc_ctx* c = ctxs[g];
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t nl = l_cut[g + 1] - l_cut[g], no = o_cut[g + 1] - o_cut[g];
@@ -1845,9 +1966,9 @@ ACMPC_API int acmpc_aggregate_sharded(acmpc_ctx* const* ctxs, acmpc_comm* const*
     hipStream_t st = nullptr;
     HIPCHK(c, hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), st));
     if (nl > 0) {
-      HIPCHK(c, hipMemcpyAsync(c->s_order_id.p, order_id + l_cut[g], (size_t)nl * 4, hipMemcpyHostToDevice, st));
-      HIPCHK(c, hipMemcpyAsync(c->s_product_idx.p, product_idx + l_cut[g], (size_t)nl * 4, hipMemcpyHostToDevice, st));
-      HIPCHK(c, hipMemcpyAsync(c->s_qty.p, qty + l_cut[g], (size_t)nl * 4, hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(c->s_order_id.p, src_id + l_cut[g], (size_t)nl * 4, hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(c->s_product_idx.p, src_pr + l_cut[g], (size_t)nl * 4, hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(c->s_qty.p, src_q + l_cut[g], (size_t)nl * 4, hipMemcpyHostToDevice, st));
     }
     if (no > 0) HIPCHK(c, hipMemcpyAsync(c->s_order_customer.p, order_customer + o_cut[g], (size_t)no * 4, hipMemcpyHostToDevice, st));
     return aggregate_device_impl(c, c->s_order_id.p, c->s_product_idx.p, c->s_qty.p, nl, c->s_order_customer.p, no,
@@ -1885,4 +2006,5 @@ ACMPC_API int acmpc_aggregate_sharded(acmpc_ctx* const* ctxs, acmpc_comm* const*
       if (ctxs[g] != ctx0) fail(ctx0, worst, "shard %d: %s", g, ctxs[g]->err);
     }
   return worst;
+  });
 }

@@ -53,6 +53,41 @@ def cortes(order_id: np.ndarray, order_id_base: int, n_orders: int, world: int) 
     return out
 
 
+def cortes_c(order_id: np.ndarray, order_id_base: int, n_orders: int, world: int,
+             line_order: int = _lib.ORDER_GROUPED) -> List[Corte]:
+    """The same cuts from the library itself (`acmpc_shard_plan`, host only: no GPU is needed): what
+    `acmpc_aggregate_sharded` uses.  With rows in any order the line ranges are the shards' places after
+    `particion_c`."""
+    lib = _lib.load()
+    oid = np.ascontiguousarray(order_id, np.int32)
+    o_cut = np.zeros(world + 1, np.int64)
+    l_cut = np.zeros(world + 1, np.int64)
+    rc = lib.acmpc_shard_plan(oid.ctypes.data, oid.size, int(n_orders), int(order_id_base), int(world), int(line_order),
+                              o_cut.ctypes.data, l_cut.ctypes.data)
+    if rc != 0:
+        from .lote import ErrorLote
+        raise ErrorLote(rc, lib.acmpc_last_error(None).decode())
+    return [Corte(int(o_cut[g]), int(o_cut[g + 1]), int(l_cut[g]), int(l_cut[g + 1])) for g in range(world)]
+
+
+def particion_c(order_id, product_idx, qty, order_id_base: int, n_orders: int, world: int):
+    """Rows in any order brought together shard by shard (`acmpc_shard_partition`, host only): returns the
+    three permuted columns and the line cuts."""
+    lib = _lib.load()
+    oid = np.ascontiguousarray(order_id, np.int32)
+    pidx = np.ascontiguousarray(product_idx, np.int32)
+    q = np.ascontiguousarray(qty, np.int32)
+    out = [np.empty(oid.size, np.int32) for _ in range(3)]
+    l_cut = np.zeros(world + 1, np.int64)
+    rc = lib.acmpc_shard_partition(oid.ctypes.data, pidx.ctypes.data, q.ctypes.data, oid.size, int(n_orders),
+                                   int(order_id_base), int(world), out[0].ctypes.data, out[1].ctypes.data,
+                                   out[2].ctypes.data, l_cut.ctypes.data)
+    if rc != 0:
+        from .lote import ErrorLote
+        raise ErrorLote(rc, lib.acmpc_last_error(None).decode())
+    return out[0], out[1], out[2], l_cut
+
+
 def fusionar(product_y_cliente, group=None, en_curso: bool = False):
     """In-place all-reduce (sum) of the concatenated [product_qty | customer_total_cents] tensor.
 

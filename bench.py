@@ -2,6 +2,7 @@
 """Benchmark of the checkout-aggregation hot path on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          (starts the N ranks itself, as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -177,18 +178,39 @@ def cpu_baseline(ds, seconds: float):
                       f"{cores} threads in {el:.1f} s; one thread: {one / 1e9:.2f} G lines/s"}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` started plainly: run the N ranks (one process per GPU) under
+    torch.distributed.run as a CHILD process and hand back its exit code.  Rank 0's JSON line reaches the
+    caller through the inherited stdout.  Nothing in this process has touched the GPU (no HIP call, no torch
+    import), and it is never replaced by another program."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] --gpus {n} without a launcher: starting {' '.join(cmd[1:8])} ... as a child process",
+          file=sys.stderr, flush=True)
+    return subprocess.run(cmd).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     import torch
     import torch.distributed as dist
-    from ac_mpc_amd import MotorLote, reparto, sintetico
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+        raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if not torch.cuda.is_available():
+        raise SystemExit(f"[bench] rank {rank} of {world}: no GPU visible to this process; bench.py measures the HIP "
+                         "path only (there is no CPU fallback)")
+    from ac_mpc_amd import MotorLote, reparto, sintetico
     # Rehearsal on a box with fewer GPUs than ranks (never used by the driver): ACMPC_BENCH_BACKEND=gloo
     # puts every rank on ACMPC_BENCH_DEVICE and moves the one all-reduce to the CPU.
     backend = os.environ.get("ACMPC_BENCH_BACKEND", "nccl")

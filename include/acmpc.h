@@ -329,11 +329,45 @@ int acmpc_merge_group_device(acmpc_ctx* const* ctxs, acmpc_comm* const* comms, i
                              int64_t* const* d_values, int64_t count, void* const* hip_streams);
 
 /*
- * acmpc_aggregate over n_devices GPUs from one process: cuts the HOST columns on order boundaries as
- * described above, copies every shard to its device, runs the device path there, merges the product
+ * Where acmpc_aggregate_sharded cuts.  Host only: no GPU and no context are needed, and nothing is
+ * allocated.  No counterpart in the reference.  o_cut[n_devices + 1] and l_cut[n_devices + 1] receive
+ * the shards: shard g owns the order indices [o_cut[g], o_cut[g + 1]) = [floor(g*M/G), floor((g+1)*M/G))
+ * and the lines [l_cut[g], l_cut[g + 1]).
+ *   line_order ACMPC_ORDER_GROUPED: l_cut[g] is the first line whose id reaches order_id_base + o_cut[g]
+ *     (a binary search of the ascending column).  Lines whose id lies below the base stay with the first
+ *     shard that owns an order, lines past base + M with the last one; the device pass there reports
+ *     them.  The cuts never descend, so that every line belongs to exactly one shard even when the
+ *     column is not sorted after all; such a column is then reported by a shard's device pass
+ *     (ACMPC_ST_ORDER_UNSORTED or ACMPC_ST_ORDER_RANGE), never mis-sized.
+ *   line_order ACMPC_ORDER_ANY / ACMPC_ORDER_AUTO: a column that is sorted is cut as above; otherwise
+ *     shard g's lines lie anywhere, and l_cut are their places after acmpc_shard_partition has brought
+ *     the rows together shard by shard.
+ * A shard without orders (n_devices > M) gets no lines.  n_lines > 0 with n_orders == 0 is
+ * ACMPC_E_INVALID, as in acmpc_aggregate.  Errors are reported through acmpc_last_error(NULL).
+ */
+int acmpc_shard_plan(const int32_t* order_id, int64_t n_lines, int64_t n_orders, int32_t order_id_base,
+                     int n_devices, int line_order, int64_t* o_cut, int64_t* l_cut);
+
+/*
+ * Host only, like acmpc_shard_plan: the stable partition of the three line columns by shard, for rows in
+ * any order.  out_*[n_lines] receive the rows of shard 0, then shard 1, ... each shard's rows in the order
+ * in which they stood; l_cut[n_devices + 1] the places where the shards begin.  No counterpart in the
+ * reference (concurrent checkouts interleave their rows: process/confirmcompra.php:27,35-37).
+ */
+int acmpc_shard_partition(const int32_t* order_id, const int32_t* product_idx, const int32_t* qty,
+                          int64_t n_lines, int64_t n_orders, int32_t order_id_base, int n_devices,
+                          int32_t* out_order_id, int32_t* out_product_idx, int32_t* out_qty, int64_t* l_cut);
+
+/*
+ * acmpc_aggregate over n_devices GPUs from one process: cuts the HOST columns on order boundaries
+ * (acmpc_shard_plan), copies every shard to its device, runs the device path there, merges the product
  * and customer vectors with the one all-reduce, and copies the results back (order totals from their
- * shards).  Every context must hold the same product table (acmpc_set_products on each).  Same
- * arguments, results and error behaviour as acmpc_aggregate; with n_devices == 1 the results equal
+ * shards).  Every context must hold the same product table (acmpc_set_products on each) and the same
+ * ACMPC_OPT_LINE_ORDER (ACMPC_E_STATE otherwise).  With ACMPC_ORDER_ANY or ACMPC_ORDER_AUTO and more
+ * than one device, rows that are not sorted are first brought together shard by shard in host memory
+ * (acmpc_shard_partition: one counting pass and one scatter over the columns, 12 bytes per line of
+ * temporary host memory).  Same arguments, results and error behaviour as acmpc_aggregate — an unsorted
+ * column under ACMPC_ORDER_GROUPED is ACMPC_E_DATA here too; with n_devices == 1 the results equal
  * acmpc_aggregate's bit for bit (as they do for any n_devices).
  * Replaces the loops of process/carrito.php:12-18 and process/confirmcompra.php:24,35-37 like
  * acmpc_aggregate, for all carts at once and all GPUs of the node.

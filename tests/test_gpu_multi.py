@@ -2,8 +2,9 @@
 
 RCCL refuses two ranks on one device, so what can run here is every entry point with n_devices = 1 /
 world = 1: the all-reduce really goes through RCCL (a sum over one rank), and the sharded host entry
-point must equal acmpc_aggregate bit for bit.  The cut logic for more shards is covered on the CPU
-(tests/test_reparto.py) and by the shard-sum tests in test_gpu_parity.py.
+point must equal acmpc_aggregate bit for bit.  The cut logic for more shards is host-only code of the
+library and is covered on the CPU (tests/test_shard_plan.py, tests/test_reparto.py) and by the shard-sum
+tests in test_gpu_parity.py.
 """
 import ctypes as C
 
@@ -49,6 +50,42 @@ def test_sharded_host_entry_equals_plain_entry(motor1, oracle):
             reparto.agregar_repartido([motor1], coms, bad, d["product_idx"], d["qty"], d["order_customer"], d["order_id_base"], c)
         assert err.value.code == _lib.E_DATA
     finally:
+        for k in coms:
+            k.cerrar()
+
+
+@pytest.mark.parametrize("modo", [True, "auto"])
+def test_sharded_entry_honours_the_line_order_option(motor1, oracle, modo):
+    """Rows in any order through the sharded entry point: same results as the oracle (ACMPC_ORDER_ANY and
+    ACMPC_ORDER_AUTO), while under the grouped promise the same rows are a contract violation reported as
+    ACMPC_E_DATA — never a size or memory error."""
+    from ac_mpc_amd import ErrorLote, _lib, reparto
+    p, c = 2_000, 5_000
+    d = oracle.synth(300_007, p, c, zipf=1, qty_mode=1)
+    price = oracle.synth_prices(p)
+    motor1.cargar_productos(price)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(d["order_id"].size)
+    oid, pidx, qty = d["order_id"][perm], d["product_idx"][perm], d["qty"][perm]
+    etot, epq, ect, flags = oracle.aggregate(d["order_id"], d["product_idx"], d["qty"], d["order_customer"],
+                                             d["order_id_base"], c, price)
+    assert flags == 0
+    coms = reparto.comunicadores_locales([motor1])
+    try:
+        with pytest.raises(ErrorLote) as err:            # grouped promise, shuffled rows
+            reparto.agregar_repartido([motor1], coms, oid, pidx, qty, d["order_customer"], d["order_id_base"], c)
+        assert err.value.code == _lib.E_DATA
+        motor1.orden_lineas(modo)
+        got = reparto.agregar_repartido([motor1], coms, oid, pidx, qty, d["order_customer"], d["order_id_base"], c)
+        for g, e in zip(got, (etot, epq, ect)):
+            assert np.array_equal(g, e)
+        # ... and grouped rows under the same option
+        got = reparto.agregar_repartido([motor1], coms, d["order_id"], d["product_idx"], d["qty"], d["order_customer"],
+                                        d["order_id_base"], c)
+        for g, e in zip(got, (etot, epq, ect)):
+            assert np.array_equal(g, e)
+    finally:
+        motor1.orden_lineas(False)
         for k in coms:
             k.cerrar()
 

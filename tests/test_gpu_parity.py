@@ -387,13 +387,22 @@ def test_full_size_100m_lines(motor, oracle, zipf):
     np.testing.assert_array_equal(ct.cpu().numpy(), ect)
 
 
-@pytest.mark.parametrize("rank", [0, 7])
+# What the eight shard tests below leave for the merge test after them: per popularity, rank -> the shard's
+# [product_qty | customer_total] vector after the exchange step, the oracle's vector, and its bookkeeping.
+_SHARDS_1G = {0: {}, 1: {}}
+
+
+@pytest.mark.parametrize("rank", range(8))
 @pytest.mark.parametrize("zipf", [0, 1])
-def test_one_shard_of_the_1g_line_configurations(motor, oracle, zipf, rank):
-    """The per-GPU workload of the two 8-GPU configurations (1 G lines over 8 GPUs, uniform and Zipf
-    products), run on one GPU at its true shape: shard `rank` of 8 holds about 125 M lines whose global line
-    indices and order ids lie far from zero (rank 7: lines from 875 M, order ids from about 219 M).  The device
-    generator must produce exactly the oracle's slice, and the engine exactly the oracle's sums on it."""
+def test_every_shard_of_the_1g_line_configurations(motor, oracle, zipf, rank):
+    """The two 8-GPU configurations (1 G lines over 8 GPUs, uniform and Zipf products) as far as one GPU can run
+    them: all eight shards one after the other, each at its true shape (about 125 M lines whose global line
+    indices and order ids lie far from zero: shard 7 starts at line 875 M, order id about 219 M).  The device
+    generator must produce exactly the oracle's slice and the engine exactly the oracle's sums on it; the
+    shard's [product_qty | customer_total] vector goes through the exchange step of the C ABI
+    (acmpc_merge_device: RCCL, a world of one here) before it is compared."""
+    import torch
+    from ac_mpc_amd import reparto
     n_total, p, c, world = 1_000_000_000, 10_000, 100_000, 8
     ds = sintetico.generar(motor, n_total, p, c, zipf=bool(zipf), qty_mode=0, rank=rank, world=world)
     m_total = ds.n_orders_total
@@ -404,15 +413,51 @@ def test_one_shard_of_the_1g_line_configurations(motor, oracle, zipf, rank):
     for name, t in (("order_id", ds.order_id), ("product_idx", ds.product_idx), ("qty", ds.qty),
                     ("order_customer", ds.order_customer)):
         assert np.array_equal(t.cpu().numpy(), d[name]), name
-    tot, pq, ct = _device_run(motor, ds)
+    dev = ds.order_id.device
+    tot = torch.full((ds.n_orders,), -7, dtype=torch.int64, device=dev)
+    vec = torch.full((p + c,), -7, dtype=torch.int64, device=dev)
+    com = reparto.ComunicadorC(motor, 0, 1)
+    try:
+        motor.agregar_device(ds.order_id, ds.product_idx, ds.qty, ds.order_customer, ds.order_id_base, c, tot,
+                             vec[:p], vec[p:])
+        com.fusionar(vec)                                                 # the exchange step, in stream order
+        assert motor.estado() == 0
+    finally:
+        com.cerrar()
     etot, epq, ect, flags = oracle.aggregate(d["order_id"], d["product_idx"], d["qty"], d["order_customer"],
                                              d["order_id_base"], c, ds.price_cents, threads=8)
     assert flags == 0
-    np.testing.assert_array_equal(tot.cpu().numpy(), etot)
-    np.testing.assert_array_equal(pq.cpu().numpy(), epq)
-    np.testing.assert_array_equal(ct.cpu().numpy(), ect)
+    got_tot, got_vec = tot.cpu().numpy(), vec.cpu().numpy()
+    np.testing.assert_array_equal(got_tot, etot)                          # totals stay with their shard
+    np.testing.assert_array_equal(got_vec[:p], epq)
+    np.testing.assert_array_equal(got_vec[p:], ect)
     if zipf:
-        assert int(epq[0]) > 10 * int(epq[p // 2])           # the hot product really is hot in this shard
+        assert int(epq[0]) > 10 * int(epq[p // 2])                        # the hot product is hot in this shard
+    _SHARDS_1G[zipf][rank] = dict(vec=got_vec, expect=np.concatenate([epq, ect]), sum_totals=int(got_tot.sum()),
+                                  line_lo=d["line_lo"], n_lines=ds.n_lines, order_lo=lo, n_orders=ds.n_orders,
+                                  m_total=m_total)
+
+
+@pytest.mark.parametrize("zipf", [0, 1])
+def test_merge_of_all_eight_shards_of_the_1g_line_configurations(oracle, zipf):
+    """The eight vectors summed on the host, which is what the all-reduce of eight ranks computes: equal to the sum
+    of the oracle's slices, every one of the 10^9 lines counted once, the money conserved; the shards tile the set."""
+    got = _SHARDS_1G[zipf]
+    if sorted(got) != list(range(8)):
+        pytest.skip("needs the eight shard tests before it in the same run")
+    n_total, p = 1_000_000_000, 10_000
+    lines, orders = 0, 0
+    for rank in range(8):
+        assert got[rank]["line_lo"] == lines and got[rank]["order_lo"] == orders
+        lines += got[rank]["n_lines"]
+        orders += got[rank]["n_orders"]
+    assert lines == n_total and orders == got[0]["m_total"]
+    merged = sum(got[r]["vec"] for r in range(8))
+    np.testing.assert_array_equal(merged, sum(got[r]["expect"] for r in range(8)))
+    assert int(merged[:p].sum()) == n_total                               # qty == 1 on every one of the 10^9 lines
+    sum_totals = sum(got[r]["sum_totals"] for r in range(8))
+    assert int(merged[p:].sum()) == sum_totals == int((merged[:p] * oracle.synth_prices(p)).sum())
+    got.clear()
 
 
 def test_first_call_of_a_context_on_a_side_stream(oracle):

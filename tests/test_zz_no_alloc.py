@@ -55,6 +55,44 @@ def test_two_calls_in_a_row_second_smaller(monkeypatch, oracle, fuse):
         m.cerrar()
 
 
+def test_a_warm_call_leaves_free_device_memory_unchanged(oracle):
+    """Nothing is allocated or freed: the device's free memory is the same before and after a call on a
+    context that is warm (hipMemGetInfo through torch, which itself allocates nothing for the query)."""
+    import torch
+    from ac_mpc_amd import MotorLote, sintetico
+    m = MotorLote(0)
+    try:
+        p, c = 10_000, 100_000
+        ds = sintetico.generar(m, 4_000_001, p, c, zipf=True, qty_mode=1)
+        dev = ds.order_id.device
+        tot = torch.zeros(ds.n_orders, dtype=torch.int64, device=dev)
+        pq = torch.zeros(p, dtype=torch.int64, device=dev)
+        ct = torch.zeros(c, dtype=torch.int64, device=dev)
+        run = lambda: m.agregar_device(ds.order_id, ds.product_idx, ds.qty, ds.order_customer, ds.order_id_base, c,
+                                       tot, pq, ct, sin_reservas=True)
+        run()
+        assert m.estado() == 0
+        torch.cuda.synchronize()
+        free_before, _ = torch.cuda.mem_get_info(dev)
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        free_after, _ = torch.cuda.mem_get_info(dev)
+        assert free_after == free_before
+        assert m.estado() == 0
+        # the allocating entry point on a fresh, larger problem does move it (the check can see an allocation)
+        m2 = MotorLote(0)
+        try:
+            m2.cargar_productos(ds.price_cents)
+            m2.agregar_device(ds.order_id, ds.product_idx, ds.qty, ds.order_customer, ds.order_id_base, c, tot, pq, ct)
+            torch.cuda.synchronize()
+            assert torch.cuda.mem_get_info(dev)[0] < free_after
+        finally:
+            m2.cerrar()
+    finally:
+        m.cerrar()
+
+
 def test_limits_are_refused_with_a_message(oracle):
     import torch
     from ac_mpc_amd import MotorLote, _lib, sintetico
