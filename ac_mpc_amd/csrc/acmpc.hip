@@ -141,6 +141,7 @@ struct acmpc_ctx {
   // Read once at init, and only when ACMPC_DEV_ABLATE=1 is set as well.
   int ablate_fix = 0, ablate_k2 = 0, ablate_ing = 0;
   int force_global_tables = 0;
+  int ing_blocks = 0;           // developer switch: workgroups of the text ingest (ACMPC_ING_BLOCKS; 0 = what fits the chip)
   int line_order = ACMPC_ORDER_GROUPED;
 
   // page-locked host buffers handed out by acmpc_host_alloc
@@ -922,6 +923,7 @@ ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
   ctx->k2_cus = env_int("ACMPC_K2_CUS", 0);
   if (ctx->k2_threads != 256 && ctx->k2_threads != 512 && ctx->k2_threads != 1024) ctx->k2_threads = 1024;
   ctx->force_global_tables = env_int("ACMPC_FORCE_GLOBAL_TABLES", 0);
+  ctx->ing_blocks = std::max(0, std::min(env_int("ACMPC_ING_BLOCKS", 0), 1 << 16));
   if (device < kMaxDevices && !g_scratch_ptr[device].load(std::memory_order_acquire)) {
     // `device` is current here.  The array's name is not a device address: this call returns the one the
     // kernels can use on this device.  A failure only matters to the allocation-free entry point, which then
@@ -1488,7 +1490,10 @@ ACMPC_API int acmpc_ingest_detalle_device(acmpc_ctx* ctx, const char* d_text, in
   }
   // entries and tickets start at zero
   HIPCHK(ctx, hipMemsetAsync(ctx->d_chunk_rows.p, 0, ((size_t)a.n_chunks + kTicketWords64) * 8, st));
-  const int blocks = (int)std::min<int64_t>(a.n_chunks, (int64_t)ctx->n_cu * kIngBlocksPerCu);
+  // (any grid size gives the same rows: fewer workgroups than stripes, or more than the chip holds at once —
+  // see the forward-progress note in acmpc_ingest.hpp; the switch exists so that a test can run both)
+  const int blocks = (int)std::min<int64_t>(a.n_chunks, ctx->ing_blocks > 0 ? (int64_t)ctx->ing_blocks
+                                                                             : (int64_t)ctx->n_cu * kIngBlocksPerCu);
   a.n_stripes = std::min(blocks, kIngStripes);
   if (a.ablate) hipLaunchKernelGGL(k_ingest_parse<true>, dim3(blocks), dim3(kIngThreads), 0, st, a);
   else hipLaunchKernelGGL(k_ingest_parse<false>, dim3(blocks), dim3(kIngThreads), 0, st, a);

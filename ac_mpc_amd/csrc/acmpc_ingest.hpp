@@ -112,12 +112,24 @@ __device__ __forceinline__ int ing_statement_row(const unsigned char* text, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row base of a chunk without a counting pass: chunks are taken in order from a ticket counter, every
-// chunk publishes its row count as soon as it knows it, and looks back over its predecessors' entries
-// (512 at a time) until it meets one that already holds an inclusive prefix.  An entry is one 64-bit
-// word: the top two bits say empty / own count / inclusive prefix, the rest is the value, so one
-// relaxed atomic store publishes both.  A chunk only ever waits for chunks with smaller tickets, which
-// were handed to workgroups that are already running.
+// Row base of a chunk without a counting pass: chunks are taken in text order WITHIN A STRIPE (chunk c
+// belongs to stripe c % n_stripes, every stripe has a ticket counter of its own), every chunk publishes
+// its row count as soon as it knows it (before its workgroup waits for anything), and looks back over its
+// predecessors' entries (64 at a time) until it meets one that already holds an inclusive prefix.  An
+// entry is one 64-bit word: the top two bits say empty / own count / inclusive prefix, the rest is the
+// value, so one relaxed atomic store publishes both.
+// Forward progress.  A chunk waits only for chunks in front of it.  Take the first chunk c* of the text
+// that is not published.  If a workgroup has drawn it, that workgroup publishes it without waiting for
+// anyone.  If nobody has, c* is the next ticket of its stripe, so it lies past every chunk the stripe's
+// workgroups hold; those workgroups wait only for chunks in front of the ones they hold, all of which are
+// published (they lie in front of c*), so they run on and one of them draws c*.  This needs every stripe to
+// have a workgroup that is running: the grid has at least n_stripes workgroups, workgroup b serves stripe
+// b % n_stripes, and the hardware starts workgroups in index order, so workgroups 0 .. n_stripes - 1 are
+// resident from the start and stay until their stripe has no ticket left.  Any grid size is therefore safe,
+// also fewer workgroups than stripes would be (n_stripes is then the grid size) and more workgroups than the
+// chip holds at once (the late ones start when a stripe is exhausted, draw a ticket past the end and leave).
+// Should a dispatcher ever start workgroups out of order, the wait is bounded: it gives up after 2^24 polls
+// and reports kStInternal instead of hanging.
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned long long kIngOwn = 1ull << 62, kIngInclusive = 2ull << 62, kIngValue = (1ull << 62) - 1ull;
 constexpr uint32_t kStInternal = 64u;

@@ -62,6 +62,9 @@ class consultasLote {
                             int32_t order_id_base, int32_t n_customers,
                             int64_t* out_order_total_cents, int64_t* out_product_qty,
                             int64_t* out_customer_total_cents);
+        int acmpc_set_option(acmpc_ctx* ctx, int option, int64_t value);
+        int acmpc_shard_plan(const int32_t* order_id, int64_t n_lines, int64_t n_orders, int32_t order_id_base,
+                            int n_devices, int line_order, int64_t* o_cut, int64_t* l_cut);
     ";
 
     /* Every GPU of the node: contexts [0] = the one of conectar(), communicator ranks beside them. */
@@ -189,6 +192,35 @@ class consultasLote {
         for ($i = 0; $i < self::$nProductos; $i++) $DeltaStock[] = $pq[$i];
         for ($i = 0; $i < $nClientes; $i++) $TotalCliente[] = $ct[$i];
         return [$TotalPagar, $DeltaStock, $TotalCliente];
+    }
+
+    /*
+     * What the caller promises about the detalle rows, on every GPU that is open: 0 = rows of one order
+     * contiguous and NumPedido ascending (the order of process/confirmcompra.php:35-37 when checkouts do not
+     * overlap; the default), 1 = no promise (concurrent checkouts interleave their rows,
+     * process/confirmcompra.php:27,35-37), 2 = try the grouped pass first.  Same results in every mode.
+     */
+    public static function OrdenLineas($modo) {
+        self::conectar();
+        self::comprobar(self::$ffi->acmpc_set_option(self::$ctx, 1 /* ACMPC_OPT_LINE_ORDER */, $modo), "fijar el orden de las lineas");
+        for ($g = 1; self::$ctxs !== null && $g < self::$nGpus; $g++)
+            self::comprobar(self::$ffi->acmpc_set_option(self::$ctxs[$g], 1, $modo), "fijar el orden de las lineas");
+    }
+
+    /*
+     * Where AgregarDetalleRepartido cuts: [[first order, ...], [first line, ...]] of every GPU plus the ends.
+     * Host arithmetic only (no GPU work): a worker can size its exports with it.
+     */
+    public static function PlanReparto($NumPedido, $nPedidos, $primerPedido, $nGpus, $modo = 0) {
+        self::conectar();
+        $oid = self::columna("int32_t", $NumPedido);
+        $oc = self::$ffi->new("int64_t[" . ($nGpus + 1) . "]");
+        $lc = self::$ffi->new("int64_t[" . ($nGpus + 1) . "]");
+        $rc = self::$ffi->acmpc_shard_plan($oid, count($NumPedido), $nPedidos, $primerPedido, $nGpus, $modo, $oc, $lc);
+        if ($rc != 0) die("Problemas al repartir el lote: " . FFI::string(self::$ffi->acmpc_last_error(null)));
+        $pedidos = []; $lineas = [];
+        for ($g = 0; $g <= $nGpus; $g++) { $pedidos[] = $oc[$g]; $lineas[] = $lc[$g]; }
+        return [$pedidos, $lineas];
     }
 
     /* CodigoProd of every product, in the order of CargarProductos (varchar(30), store.sql:110). */

@@ -170,6 +170,26 @@ def test_dense_rows_empty_chunks_and_long_rows_keep_their_order(motor, oracle):
     _same(motor, oracle, text, codes)
 
 
+@pytest.mark.parametrize("blocks", [1, 3, 8, 20000])
+def test_any_grid_size_gives_the_same_rows(monkeypatch, oracle, blocks):
+    """Chunk tickets are drawn per stripe, so a chunk can wait for one that no workgroup has drawn yet; what
+    keeps that safe is that every stripe always has a running workgroup.  Run the ingest with fewer workgroups
+    than stripes (1, 3), exactly one per stripe (8) and far more than the chip holds at once (the grid is then
+    one workgroup per chunk): the same rows as the oracle, and the bounded wait never gives up."""
+    from ac_mpc_amd import MotorLote
+    monkeypatch.setenv("ACMPC_ING_BLOCKS", str(blocks))
+    m = MotorLote(0)
+    try:
+        n = 1_200_003                                      # about 30 MB of text: 2.5 k chunks of 12 KiB
+        d = oracle.synth(n, 10_000, 50, zipf=1, qty_mode=1)
+        codes = [ic.code_of(p) for p in range(10_000)]
+        text = ic.render(d["order_id"].tolist(), d["product_idx"].tolist(), d["qty"].tolist(), "dump")
+        assert len(text) // 12288 > 2000
+        _same(m, oracle, text, codes)                      # (an ACMPC_ST_INTERNAL would surface as ErrorLote)
+    finally:
+        m.cerrar()
+
+
 def test_capacity_too_small_is_reported(motor):
     ingesta.cargar_codigos(motor, ["1"])
     with pytest.raises(ErrorLote) as e:
