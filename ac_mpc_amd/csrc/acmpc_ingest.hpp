@@ -81,10 +81,34 @@ __device__ __forceinline__ uint32_t ing_bytes_eq(uint32_t w, uint32_t c4) {
   const uint32_t x = w ^ c4;
   return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
 }
+// The statement exactly as library/consulSQL.php:30 builds it from the arguments of process/confirmcompra.php:36:
+// "insert into detalle (NumPedido, CodigoProd, CantidadProductos) VALUES(" — 70 bytes, the row's '(' at offset 69 —
+// as little-endian words.  A line that begins with these bytes needs no search: its only earlier '(' follows
+// "detalle", not "values", and there is no newline in between, so the search below would return 69 as well.
+constexpr int kIngCanonAt = 69;
+constexpr int kIngCanonWords = 18;
+__device__ __forceinline__ bool ing_canonical_statement(const unsigned char* text, int pos) {
+  constexpr uint32_t canon[kIngCanonWords] = {
+      0x65736e69u, 0x69207472u, 0x206f746eu, 0x61746564u, 0x20656c6cu, 0x6d754e28u, 0x69646550u, 0x202c6f64u, 0x69646f43u,
+      0x72506f67u, 0x202c646fu, 0x746e6143u, 0x64616469u, 0x646f7250u, 0x6f746375u, 0x56202973u, 0x45554c41u, 0x00002853u};
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(text) + (pos >> 2);
+  const uint32_t sh = (uint32_t)pos & 3u;
+  uint32_t x[kIngCanonWords + 1];
+#pragma unroll
+  for (int i = 0; i <= kIngCanonWords; ++i) x[i] = w[i];             // (none of these reads depends on another)
+  uint32_t diff = 0u;
+#pragma unroll
+  for (int i = 0; i < kIngCanonWords; ++i) {
+    const uint32_t d = __builtin_amdgcn_alignbyte(x[i + 1], x[i], sh) ^ canon[i];
+    diff |= i == kIngCanonWords - 1 ? (d & 0xffffu) : d;             // the last word holds the prefix's last two bytes
+  }
+  return diff == 0u;
+}
 // `text` is the (4-byte aligned) LDS text, `pos` the offset of the line start in it.  The line is searched
 // a word at a time for '(' and newline; four words are requested together (the reads of one step do not
 // depend on each other).
 __device__ __forceinline__ int ing_statement_row(const unsigned char* text, int pos) {
+  if (ing_canonical_statement(text, pos)) return kIngCanonAt;
   const unsigned char* s = text + pos;
   if (!ing_lower_is(s, "insert")) return -1;
   const uint32_t* w = reinterpret_cast<const uint32_t*>(text);
@@ -539,6 +563,15 @@ struct IngOwn {
 };
 
 constexpr int kIngBuf = kIngFront + kIngChunk + kIngLook + 64;
+// A chunk with at most this many data rows (long lines: one-statement-per-line text has a row every 98 bytes, 125 a
+// chunk) hands its rows out by rank in the chunk, one to a lane (wave w takes rows 64 w + lane), instead of leaving
+// every row to the thread in whose 48 bytes it starts: the lanes of the first waves are then all busy and the waves
+// past the last row skip the parse, where otherwise every wave runs the automaton for the few lanes that own a row.
+// (Two rows to a lane, which would also serve the dump style's 480 rows a chunk, was measured and lost: a chunk's
+// time is the time of its busiest wave, and one wave with two rows per lane takes longer than two waves with one.)
+constexpr int kIngSparse = kIngThreads;
+constexpr int kIngLookWave = 0;                            // the wave that looks back over the chunks in front for the row base
+constexpr int kWaveRows = 64;                              // rows of one wave-instruction in the rank-based parse
 
 // Every thread owns 48 bytes of a 12 KiB chunk and parses the rows that START there (a row of the shapes the
 // reference writes takes 19..26 bytes, so a thread has one to three of them; any other mix only changes how
@@ -558,6 +591,7 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
   __shared__ int s_w[kIngThreads / 64];
   __shared__ long long s_tk[2];
   __shared__ long long s_base[2], s_base_of[2];            // row base of a chunk, and which chunk (+ 1) it belongs to
+  __shared__ unsigned short s_list[2][kIngSparse];         // chunks of few rows: where the row of every rank starts in s_text
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < kIngTableWords; i += kIngThreads) {
     const unsigned long long e = a.tables[i];
@@ -674,6 +708,17 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
       nxt.first += woff;
       // publish as early as possible: successors add this count up long before this chunk knows its base
       if (tid == 0 && !(ablate & 64)) ing_publish_own(a.chunk_state, c_next, n_next);
+      if (n_next <= kIngSparse) {                          // uniform: few rows, handed out by rank when the chunk is parsed
+        const unsigned char* t = s_text[buf] + kIngFront;
+        uint32_t at = nxt.stmt_at;
+        int r = nxt.first;                                 // ranks of this thread's rows: [first, first + its rows) < n_next
+        for (unsigned long long mm = nxt.rows; mm; mm &= mm - 1ull) {
+          const int k = __ffsll((long long)mm) - 1;
+          int p = kIngFront + o + k;
+          if (at != 0u && (t[o + k] | 0x20u) == (uint32_t)'i') { p += (int)(at & 0xffu); at >>= 8; }   // (as take() below)
+          s_list[buf][r++] = (unsigned short)p;
+        }
+      }
       c_after = s_tk[par];
       if (c_after < a.n_chunks) {
         request_text(c_after);
@@ -683,15 +728,16 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
       }
     }
     if (c_cur >= 0) {
-      // Wave 0 looks back over the counts of the chunks in front and hands the row base to the other waves
-      // through LDS, where they wait for it (no barrier: wave 0 never waits for them, and polling LDS costs
-      // the memory side nothing).  The first round of its loads is issued here and used after the first rows
-      // have been through the automaton, which needs no row base.
+      // One wave (kIngLookWave) looks back over the counts of the chunks in front and hands the row base to the
+      // other waves through LDS, where they wait for it (no barrier: that wave never waits for them, and polling
+      // LDS costs the memory side nothing).  The first round of its loads is issued here and used after its first
+      // rows have been through the automaton, which needs no row base.  (Issued a whole staging and discovery phase
+      // earlier, at the top of the iteration, the answer is older and as often incomplete: measured, no gain.)
       unsigned long long look = kIngInclusive;
-      if (wave == 0 && !(ablate & 64)) look = ing_look_first(a.chunk_state, c_cur, lane);
+      if (wave == kIngLookWave && !(ablate & 64)) look = ing_look_first(a.chunk_state, c_cur, lane);
       auto row_base = [&]() -> long long {
         long long rbase;
-        if (wave == 0) {
+        if (wave == kIngLookWave) {
           rbase = (ablate & 64) ? c_cur * 400 : ing_row_base(a.chunk_state, c_cur, n_cur, lane, a.status, look);
           if (lane == 0) {
             s_base[par] = rbase;
@@ -709,8 +755,12 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
         return rbase;
       };
       const unsigned char* tx = s_text[buf ^ 1];
-      unsigned long long m = cur.rows;
-      uint32_t at = cur.stmt_at;
+      // A chunk of few rows hands them out by rank, one to a thread (thread r takes row r, whose place the list
+      // holds); otherwise every thread parses the rows that start in its own 48 bytes.
+      const bool sparse = n_cur <= kIngSparse;             // uniform
+      unsigned long long m = sparse ? (tid < n_cur ? 1ull : 0ull) : cur.rows;
+      uint32_t at = sparse ? 0u : cur.stmt_at;
+      const int first_row = sparse ? tid : cur.first;
       long long row = -1;                                  // output row of the lane's next data row, once the base is known
       auto take = [&](bool& have) -> int {
         have = m != 0ull;
@@ -718,6 +768,7 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
         int p = kIngFront + o + k;
         if (have && at != 0u && (tx[p] | 0x20u) == (uint32_t)'i') { p += (int)(at & 0xffu); at >>= 8; }
         m &= m - 1ull;
+        if (sparse) p = have ? (int)s_list[buf ^ 1][tid] : kIngFront;
         return p;
       };
       auto emit = [&](bool have, int p, uint32_t st16, uint32_t A, uint32_t B, bool wide) {
@@ -736,7 +787,10 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
         return ((A >> kANd1) & 127u) <= 8u && ((A >> kANd2) & 127u) <= 4u && ((A >> kACl) & 127u) <= 12u;
       };
       // two rows of the lane go through the automaton together while any lane has two left (the table
-      // look-ups of one row depend on each other; a second row fills the waits)
+      // look-ups of one row depend on each other; a second row fills the waits).  With rows handed out by rank a
+      // wave past the last row has nothing to do (the wave that looks back always goes through: it publishes the
+      // chunk's prefix whether or not the chunk has rows).
+      if (!sparse || wave == kIngLookWave || wave * kWaveRows < n_cur)      // wave-uniform
       do {
         bool have[2];
         int p[2];
@@ -754,7 +808,7 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
           st16[0] = s1[0]; A[0] = A1[0]; B[0] = B1[0];
           st16[1] = sDone * kStUnit; A[1] = 0; B[1] = 0;
         }
-        if (row < 0) row = row_base() + cur.first;          // uniform: the first pass of this chunk
+        if (row < 0) row = row_base() + first_row;          // uniform: the first pass of this chunk
         // the cheaper conversion when no row of the wave has a long number or a long code
         const bool wide = __ballot((have[0] && !plain(A[0])) || (have[1] && !plain(A[1]))) != 0ull;
         emit(have[0], p[0], st16[0], A[0], B[0], wide);

@@ -190,6 +190,54 @@ def test_any_grid_size_gives_the_same_rows(monkeypatch, oracle, blocks):
         m.cerrar()
 
 
+def test_chunks_either_side_of_the_rows_by_rank_limit(motor, oracle):
+    """A 12 KiB chunk with at most 256 data rows hands them to the threads by rank; a chunk with more leaves every
+    row to the thread in whose 48 bytes it starts.  Rows of exactly 48 bytes put 256 rows in every chunk; a byte
+    more or less per row moves chunks to either side of the limit, and so do stretches of other row lengths
+    between them.  Statement lines as the reference writes them (library/consulSQL.php:30) are mixed with
+    statement lines whose front part is not the reference's, which take the general search."""
+    rng = np.random.default_rng(SEED + 59)
+    codes = ["1", "2", "3", "SKU-1"]
+    parts, k = [], 0
+
+    def padded(n_rows, width):
+        nonlocal k
+        out = []
+        for i in range(n_rows):
+            body = f"({k + i}, '{codes[(k + i) % 4]}', {1 + i % 9}"
+            out.append(body + " " * (width - 2 - len(body)) + ")\n")      # (spaces may stand in front of the ')')
+        k += n_rows
+        return "".join(out)
+
+    for block in range(60):
+        kind = block % 6
+        if kind == 0:
+            parts.append(padded(int(rng.integers(300, 900)), 48))          # exactly 256 rows a chunk
+        elif kind == 1:
+            parts.append(padded(int(rng.integers(300, 900)), 47))          # 261 rows a chunk: every thread its own rows
+        elif kind == 2:
+            parts.append(padded(int(rng.integers(300, 900)), 49))          # 250 rows a chunk: rows by rank
+        elif kind == 3:
+            n = int(rng.integers(100, 400))
+            parts.append("".join(f"insert into detalle (NumPedido, CodigoProd, CantidadProductos) VALUES('{k + i}', '{codes[i % 4]}', '1')\n"
+                                 for i in range(n)))
+            k += n
+        elif kind == 4:
+            n = int(rng.integers(100, 400))
+            fronts = ["INSERT INTO detalle (NumPedido, CodigoProd, CantidadProductos) VALUES",
+                      "insert into detalle (NumPedido, CodigoProd, CantidadProductos)  VALUES ",
+                      "insert into detalle (NumPedido, CodigoProd, CantidadProductos) values",
+                      "insert into detalle (NumPedido, CodigoProd, CantidadProductos) VALUE",      # no row: skipped
+                      "insert into detalle (NumPedido, CodigoProd, CantidadProductoz) VALUES"]
+            parts.append("".join(f"{fronts[i % 5]}('{k + i}', '{codes[i % 4]}', '1')\n" for i in range(n)))
+            k += n
+        else:
+            parts.append("-- nothing\n" * int(rng.integers(1000, 3000)))   # chunks without any row
+    text = "".join(parts).encode()
+    assert len(text) > 100 * 12288
+    _same(motor, oracle, text, codes)
+
+
 def test_capacity_too_small_is_reported(motor):
     ingesta.cargar_codigos(motor, ["1"])
     with pytest.raises(ErrorLote) as e:
