@@ -22,6 +22,7 @@ EXPORTS = (
     "acmpc_host_alloc", "acmpc_host_free", "acmpc_aggregate_device_noalloc",
     "acmpc_comm_id", "acmpc_comm_init_rank", "acmpc_comm_init_all", "acmpc_comm_destroy", "acmpc_merge_device",
     "acmpc_merge_group_device", "acmpc_aggregate_sharded", "acmpc_shard_plan", "acmpc_shard_partition",
+    "acmpc_last_line_order_path",
 )
 
 OK, E_INVALID, E_HIP, E_ALIGN, E_DATA, E_STATE, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
@@ -30,6 +31,7 @@ ST_EMIT_CAPACITY, ST_INTERNAL = 32, 64
 EMIT_SQL, EMIT_CSV, EMIT_DISPLAY = 0, 1, 2
 ORDER_COUNTS, DESCUENTO_UNITS, DESCUENTO_PERCENT = 1, 0, 1
 OPT_LINE_ORDER, ORDER_GROUPED, ORDER_ANY, ORDER_AUTO = 1, 0, 1, 2
+PATH_NONE, PATH_ATOMIC, PATH_MOVED, PATH_MOVED_STOCK, PATH_GROUPED = -1, 0, 1, 2, 3
 K_LINES, K_FIXUP, K_CUSTOMERS, K_CUSTMERGE, N_KERNELS = 0, 1, 2, 3, 4
 
 
@@ -116,6 +118,8 @@ def load() -> C.CDLL:
     lib.acmpc_shard_plan.restype = C.c_int
     lib.acmpc_shard_partition.argtypes = [vp, vp, vp, i64, i64, i32, C.c_int, vp, vp, vp, vp]
     lib.acmpc_shard_partition.restype = C.c_int
+    lib.acmpc_last_line_order_path.argtypes = [vp, vp, C.POINTER(C.c_int)]
+    lib.acmpc_last_line_order_path.restype = C.c_int
     lib.acmpc_status.argtypes = [vp, vp, u32p]
     lib.acmpc_status.restype = C.c_int
     lib.acmpc_set_option.argtypes = [vp, C.c_int, i64]

@@ -98,6 +98,8 @@ struct acmpc_ctx {
   DevBuf<unsigned long long> d_part_rec[2];   // records of the order-restoring path after its two scatter passes
   DevBuf<unsigned long long> d_part_meta;
   int partition = 1;                // 0: rows in any order always go through the atomic kernel (ACMPC_PARTITION=0)
+  bool part_ran = false;            // the last aggregate call queued the order-restoring path (its mode word says what it did)
+  unsigned long long* d_part_mode = nullptr;   // that word (inside d_part_meta)
   DevBuf<unsigned long long> d_cust_carry;
   uint32_t* d_status = nullptr;
   bool carry_dirty = false;     // a launch failed half way: clear the carries before the next call
@@ -142,6 +144,7 @@ struct acmpc_ctx {
   // Read once at init, and only when ACMPC_DEV_ABLATE=1 is set as well.
   int ablate_fix = 0, ablate_k2 = 0, ablate_ing = 0;
   int force_global_tables = 0;
+  int part_shift = 0;           // developer switch: at least 2^this orders per bucket of the order-restoring path (ACMPC_PART_SHIFT)
   int ing_blocks = 0;           // developer switch: workgroups of the text ingest (ACMPC_ING_BLOCKS; 0 = what fits the chip)
   int line_order = ACMPC_ORDER_GROUPED;
 
@@ -448,7 +451,7 @@ constexpr size_t kPartLdsB = (size_t)2 * (kPartMaxBuckets + 4) * 4 + (size_t)kPa
 
 bool partition_fits(const acmpc_ctx* ctx, const LinesPlan& lp, int64_t n_orders) {
   return ctx->partition && !ctx->force_global_tables && lp.lds_tables && lp.price_lds && lp.hist_lds && lp.price32 &&
-         n_orders <= (int64_t)kPartMaxBuckets * kPartBucket &&
+         n_orders <= ((int64_t)kPartMaxBuckets << kPartMaxShift) &&
          (size_t)ctx->p_pad * 8 + kPartLdsA + kLdsReserve <= (size_t)kMaxLds;
 }
 
@@ -466,21 +469,31 @@ int launch_partition(acmpc_ctx* ctx, PartArgs& a, int blocks, hipStream_t st) {
   a.changes = a.cursor_a + kPartCoarse;
   a.descents = a.changes + 1;
   a.mode = a.changes + 2;
+  ctx->d_part_mode = a.mode;
   a.rec_a = ctx->d_part_rec[0].p;
   a.rec_b = ctx->d_part_rec[1].p;
-  a.n_buckets = (int32_t)((a.n_orders + kPartBucket - 1) / kPartBucket);
+  // at most 2048 buckets: 16384 orders each up to 2^25 orders, 32768 up to 2^26, 65536 up to 2^27 (partition_fits)
+  a.shift = std::max((int)kPartShift, ctx->part_shift);     // (the switch lets small inputs exercise the larger buckets)
+  while (((int64_t)kPartMaxBuckets << a.shift) < a.n_orders) ++a.shift;
+  a.val_bits = 64 - 11 - a.shift;
+  a.n_buckets = (int32_t)(((int64_t)a.n_orders + ((int64_t)1 << a.shift) - 1) >> a.shift);
   HIPCHK(ctx, hipMemsetAsync(a.counts, 0, (size_t)kPartMaxBuckets * 8, st));
   HIPCHK(ctx, hipMemsetAsync(a.changes, 0, 16, st));     // changes and descents
   hipLaunchKernelGGL(k_part_count, dim3(blocks), dim3(kPartThreads), 0, st, a);
   hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(kPartThreads), 0, st, a);
   const size_t lds_a = (size_t)ctx->p_pad * 8 + kPartLdsA;
-  if ((rc = set_dyn_lds(ctx, k_part_scatter_a, lds_a))) return rc;
-  hipLaunchKernelGGL(k_part_scatter_a, dim3(blocks), dim3(kPartThreads), lds_a, st, a);
+  if (a.line_price || a.order_state) {
+    if ((rc = set_dyn_lds(ctx, k_part_scatter_a<true>, lds_a))) return rc;
+    hipLaunchKernelGGL(k_part_scatter_a<true>, dim3(blocks), dim3(kPartThreads), lds_a, st, a);
+  } else {
+    if ((rc = set_dyn_lds(ctx, k_part_scatter_a<false>, lds_a))) return rc;
+    hipLaunchKernelGGL(k_part_scatter_a<false>, dim3(blocks), dim3(kPartThreads), lds_a, st, a);
+  }
   if ((rc = set_dyn_lds(ctx, k_part_scatter_b, kPartLdsB))) return rc;
   hipLaunchKernelGGL(k_part_scatter_b, dim3(blocks), dim3(kPartThreads), kPartLdsB, st, a);
   const size_t lds_c = (size_t)kPartBucket * 8;
   if ((rc = set_dyn_lds(ctx, k_part_reduce, lds_c))) return rc;
-  hipLaunchKernelGGL(k_part_reduce, dim3(std::max(1, a.n_buckets)), dim3(kPartThreads), lds_c, st, a);
+  hipLaunchKernelGGL(k_part_reduce, dim3(std::max(1, a.n_buckets) << (a.shift - kPartShift)), dim3(kPartThreads), lds_c, st, a);
   HIPCHK(ctx, hipGetLastError());
   return ACMPC_OK;
 }
@@ -595,7 +608,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     HIPCHK(ctx, hipMemsetAsync(d_pq, 0, (size_t)P * 8, st));
     if (d_desc && n_orders > 0) {
       hipLaunchKernelGGL(k_order_adjust, dim3((unsigned)((n_orders + 255) / 256)), dim3(256), 0, st, d_tot, d_desc,
-                         n_orders, life->descuento_mode);
+                         n_orders, life->descuento_mode, (const unsigned long long*)nullptr);
       HIPCHK(ctx, hipGetLastError());
     }
     if (ctx->profiling) { HIPCHK(ctx, hipEventRecord(ctx->ev[1], st)); HIPCHK(ctx, hipEventRecord(ctx->ev[2], st)); }
@@ -631,6 +644,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.rec_id = w.rec_id; a.rec_sum = w.rec_sum; a.status = w.status;
     a.line_price = reinterpret_cast<const long long*>(d_line_price);
     a.price_in_lds = lp.price_lds ? 1 : 0;
+    ctx->part_ran = false;
     a.only_if_unsorted = 0;
     a.totals_only = 0;
     a.fill_edges = fused ? 1 : 0;
@@ -645,7 +659,13 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
 
     if (!fixed_ws) ctx->carry_dirty = true;      // cleared again once the merge kernels are queued
     // rows in any order: the order-restoring path when the sizes allow it, else one global atomic per run
-    const bool part_ok = !life && !fixed_ws && partition_fits(ctx, lp, n_orders);
+    // (with a line-price column the grouped kernel that takes rows which turn out grouped needs a plan of its
+    // own, with the LDS through which it re-orders the price loads; the path is only taken if both plans agree
+    // on the workgroups, whose stock-delta slabs are merged whichever kernel wrote them)
+    LinesPlan lpx = lp;
+    if (any_order && d_line_price) plan_lines(ctx, n_lines, &lpx, true);
+    const bool part_ok = !fixed_ws && partition_fits(ctx, lp, n_orders) && lpx.blocks == lp.blocks &&
+                         lpx.n_active_waves == lp.n_active_waves && lpx.tiles_per_wave == lp.tiles_per_wave && lpx.lds_tables;
     const int part_blocks = lp.blocks;
     PartArgs pa;
     memset(&pa, 0, sizeof(pa));
@@ -657,19 +677,35 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       pa.q_small = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(65536, 0xffffffffull / std::max<uint64_t>(1, per_block)));
     }
     pa.prod_carry = w.prod_carry; pa.order_total = d_tot; pa.status = w.status;
+    pa.line_price = reinterpret_cast<const long long*>(d_line_price);
+    pa.order_state = d_state;
+    pa.order_descuento = d_desc;                          // (taken off where the reduce writes the totals)
+    pa.descuento_mode = d_desc ? life->descuento_mode : 0;
+    const unsigned long long* moved_gate = nullptr;       // where the device says that the reduce wrote net totals
     if (any_order && part_ok) {
       // count + decide on the device; then either the moving passes or the atomic kernel does the work
       pa.prod_slab = w.prod_slab;                       // (lp.blocks slabs, whichever path fills them)
       if ((rc = launch_partition(ctx, pa, lp.blocks, st))) return rc;
       hipLaunchKernelGGL(k_zero_if_unsorted, dim3(ctx->n_cu * 4), dim3(256), 0, st, d_tot, n_orders, w.status, 0, pa.mode);
       HIPCHK(ctx, hipGetLastError());
+      ctx->part_ran = true;
+      moved_gate = pa.mode;
       a.run_if_zero = pa.mode;
       const size_t tables = (size_t)ctx->p_pad * 8;     // (partition_fits: both tables in LDS, 32-bit prices)
-      if ((rc = launch_lines_any<int32_t, true>(ctx, lp, tables, a, st))) return rc;
+      if (life_lines) rc = launch_lines_any<int32_t, true, true>(ctx, lp, tables, a, st);
+      else rc = launch_lines_any<int32_t, true>(ctx, lp, tables, a, st);
+      if (rc) return rc;
       a.run_if_zero = nullptr;
       // ... or, if the ids never went down, the grouped kernel (its wave-boundary records are finished by k_fixup)
       a.run_if_sorted = pa.mode;
-      if ((rc = launch_lines<int32_t, true, 4>(ctx, lp, a, st))) return rc;
+      if (d_line_price) {
+        LinesArgs ax = a;                                 // the same launch with the plan that holds the price slices
+        ax.stage_cap = lpx.stage_cap; ax.flush_reserve = lpx.flush_reserve;
+        rc = launch_lines<int64_t, true, 4, true, true>(ctx, lpx, ax, st);
+      }
+      else if (life_lines) rc = launch_lines<int32_t, true, 4, true>(ctx, lp, a, st);
+      else rc = launch_lines<int32_t, true, 4>(ctx, lp, a, st);
+      if (rc) return rc;
       a.run_if_sorted = nullptr;
       sorted_gate = pa.mode;
     }
@@ -750,6 +786,8 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
         // far (every kernel of it leaves at once if the rows were grouped after all)
         pa.totals_only = 1; pa.only_if_unsorted = 1;
         if ((rc = launch_partition(ctx, pa, lp.blocks, st))) return rc;
+        ctx->part_ran = true;
+        moved_gate = pa.mode;
         b.run_if_zero = pa.mode;
       }
       {
@@ -769,9 +807,10 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       hipLaunchKernelGGL(k_clear_unsorted, dim3(1), dim3(64), 0, st, w.status);
       HIPCHK(ctx, hipGetLastError());
     }
-    if (d_desc && !desc_in_lines) {   // totals are final after k_fixup: take the discounts off
+    if (d_desc && !desc_in_lines) {   // totals are final after k_fixup: take the discounts off (unless the reduce of the
+                                      // order-restoring path wrote them, net already)
       hipLaunchKernelGGL(k_order_adjust, dim3((unsigned)((n_orders + 255) / 256)), dim3(256), 0, st, d_tot, d_desc,
-                         n_orders, life->descuento_mode);
+                         n_orders, life->descuento_mode, moved_gate);
       HIPCHK(ctx, hipGetLastError());
     }
     if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
@@ -925,6 +964,7 @@ ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
   ctx->k2_cus = env_int("ACMPC_K2_CUS", 0);
   if (ctx->k2_threads != 256 && ctx->k2_threads != 512 && ctx->k2_threads != 1024) ctx->k2_threads = 1024;
   ctx->force_global_tables = env_int("ACMPC_FORCE_GLOBAL_TABLES", 0);
+  ctx->part_shift = std::max(0, std::min(env_int("ACMPC_PART_SHIFT", 0), (int)kPartMaxShift));
   ctx->ing_blocks = std::max(0, std::min(env_int("ACMPC_ING_BLOCKS", 0), 1 << 16));
   if (device < kMaxDevices && !g_scratch_ptr[device].load(std::memory_order_acquire)) {
     // `device` is current here.  The array's name is not a device address: this call returns the one the
@@ -1186,6 +1226,19 @@ ACMPC_API int acmpc_set_option(acmpc_ctx* ctx, int option, int64_t value) {
     return ACMPC_OK;
   }
   return fail(ctx, ACMPC_E_INVALID, "acmpc_set_option: unknown option %d or value %lld", option, (long long)value);
+}
+
+ACMPC_API int acmpc_last_line_order_path(acmpc_ctx* ctx, void* hip_stream, int* path) {
+  if (!ctx || !path) return fail(ctx, ACMPC_E_INVALID, "acmpc_last_line_order_path: null argument");
+  *path = ACMPC_PATH_NONE;
+  if (!ctx->part_ran || !ctx->d_part_mode) return ACMPC_OK;
+  ENTER_DEVICE(ctx);
+  hipStream_t st = (hipStream_t)hip_stream;
+  unsigned long long mode = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&mode, ctx->d_part_mode, sizeof(mode), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  *path = (int)mode;
+  return ACMPC_OK;
 }
 
 ACMPC_API int acmpc_set_profiling(acmpc_ctx* ctx, int enabled) {

@@ -1334,8 +1334,11 @@ __device__ __forceinline__ void custmerge_block(const CustMergeArgs& a, int bid,
   }
 }
 
+// unless_moved: when not null, the word in which the order-restoring path says what it did; 1 means that its
+// reduce wrote the totals, net of the discounts already.
 __global__ void __launch_bounds__(256) k_order_adjust(int64_t* order_total, const int32_t* descuento, int64_t n_orders,
-                                                      int mode) {
+                                                      int mode, const unsigned long long* unless_moved) {
+  if (unless_moved && *unless_moved == 1ull) return;       // uniform
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o < n_orders) {
     const long long g = order_total[o];

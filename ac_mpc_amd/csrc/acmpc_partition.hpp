@@ -5,16 +5,18 @@
 // One 64-bit global atomic per line is bound by the part's scattered-atomic rate (about 23 G/s).  Instead
 // the lines are moved next to the other lines of their order's neighbourhood, and summed there in LDS:
 //
-//   k_part_count      lines per bucket of 16384 consecutive orders (one pass over order_id), and how often
-//                     the order id changes from one line to the next
+//   k_part_count      lines per bucket of 16384 consecutive orders (32768 or 65536 beyond 2^25 / 2^26 orders: there
+//                     are at most 2048 buckets), one pass over order_id, and how often the order id changes from
+//                     one line to the next
 //   k_part_scan       bucket offsets, cursors of the two scatter passes; decides whether the rows are far
 //                     enough from grouped for this path (else k_lines_any, one atomic per run, is cheaper)
-//   k_part_scatter_a  every line becomes one 64-bit record, order index (25 bits) above price * qty (39 bits),
-//                     written into one of 32 coarse bins (64 buckets each); the stock deltas are taken here
-//                     as well.  A value outside [0, 2^39) does not fit a record: the pass then hands the
-//                     totals (not the stock deltas, which it has) to the atomic kernel
+//   k_part_scatter_a  every line becomes one 64-bit record, order index (25 to 27 bits) above price * qty (39 to
+//                     37 bits), written into one of 32 coarse bins (64 buckets each); the stock deltas are taken
+//                     here as well.  A value that does not fit its bits does not fit a record: the pass then hands
+//                     the totals (not the stock deltas, which it has) to the atomic kernel
 //   k_part_scatter_b  every coarse bin split into its buckets
-//   k_part_reduce     one workgroup per bucket: 64-bit adds into a 128 KB LDS table, totals written once
+//   k_part_reduce     one workgroup per 16384 orders: 64-bit adds into a 128 KB LDS table, totals written once (a
+//                     bucket of 32768 or 65536 orders is read by two or four workgroups, each keeping its part)
 //
 // Both scatter passes bin a round of records (4096 / 8192) in LDS and write whole runs, and reserve the place
 // of a run with one returning atomic per (round, bin): the records of a bucket end up in no particular order,
@@ -24,9 +26,10 @@
 
 namespace acmpc {
 
-constexpr int kPartShift = 14;                         // 16384 orders per bucket: int64 cells fill 128 KB of LDS
+constexpr int kPartShift = 14;                         // 16384 orders per reduce workgroup: int64 cells fill 128 KB of LDS
 constexpr int kPartBucket = 1 << kPartShift;
-constexpr int kPartMaxBuckets = 2048;                  // hence at most 2^25 orders on this path
+constexpr int kPartMaxBuckets = 2048;                  // buckets of 2^14 orders reach 2^25 orders, of 2^16 orders 2^27
+constexpr int kPartMaxShift = 16;
 constexpr int kPartCoarseShift = 6;                    // 64 buckets per coarse bin, at most 32 coarse bins
 constexpr int kPartCoarse = kPartMaxBuckets >> kPartCoarseShift;
 constexpr int kPartThreads = 1024;
@@ -41,7 +44,9 @@ struct PartArgs {
   int64_t n_lines;
   int32_t base;
   int32_t n_orders;
-  int32_t n_buckets;                  // ceil(n_orders / 16384)
+  int32_t n_buckets;                  // ceil(n_orders / 2^shift), at most kPartMaxBuckets
+  int32_t shift;                      // log2 of the orders per bucket: 14, or 15 / 16 for more than 2^25 / 2^26 orders
+  int32_t val_bits;                   // bits of a record below the order index: 64 - 11 - shift
   const int64_t* price;               // [P + 1], entry P is the null product
   int32_t n_products, p_pad;
   uint32_t q_small;                   // quantities in [0, q_small) go to the 32-bit LDS histogram
@@ -63,6 +68,12 @@ struct PartArgs {
   // 64-bit atomic per run of equal ids, k_lines_any, which costs about 0.05 ms per million runs).  Pass A sets
   // it to 2 when it meets a value that does not fit a record: the atomic kernel then redoes the order totals.
   // Rows whose ids never go down are grouped after all: mode 3, and the grouped line pass takes them.
+  // order lifecycle (each may be null): the price a line was sold at instead of the table price, whether an order
+  // counts towards the stock deltas (bit 0 of its state), and venta.Descuento, taken off where the reduce writes
+  const long long* line_price;        // [n_lines]
+  const unsigned char* order_state;   // [n_orders]
+  const int32_t* order_descuento;     // [n_orders]
+  int32_t descuento_mode;
   unsigned long long* changes;        // zero on entry of k_part_count
   unsigned long long* descents;       // zero on entry of k_part_count; nonzero: the order id goes down somewhere
   unsigned long long* mode;
@@ -79,10 +90,9 @@ __device__ __forceinline__ bool part_skip_scatter_a(const PartArgs& a) {
   return part_skip(a) || m == 0ull || m == 3ull;
 }
 
-// A record: the order index in the 25 bits above the 39 bits of the line's value.
-constexpr int kPartValBits = 39;
-constexpr unsigned long long kPartValMask = (1ull << kPartValBits) - 1ull;
-static_assert(kPartShift + 11 + kPartValBits == 64, "2048 buckets of 16384 orders: 25 bits of order index");
+// A record: the order index (11 bits of bucket number above `shift` bits inside the bucket) above the val_bits
+// bits of the line's value: 25 + 39 bits up to 2^25 orders, 26 + 38 up to 2^26, 27 + 37 up to 2^27.
+__device__ __forceinline__ unsigned long long part_val_mask(const PartArgs& a) { return (1ull << a.val_bits) - 1ull; }
 
 // Position of a lane's records among the records of their bins in this round.  The lanes of a wave that share
 // a bin take one returning add on the bin's counter between them (made by the lowest of them), so adds to one
@@ -154,7 +164,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_count(PartArgs a) {
       const bool ok = idx < (uint32_t)a.n_orders;
       if (!ok) st |= kStOrderRange;
       // rows that are grouped after all put every lane of a wave into one bucket: those lanes share one add
-      const uint32_t bucket = ok ? idx >> kPartShift : 0xffffffffu;
+      const uint32_t bucket = ok ? idx >> a.shift : 0xffffffffu;
       const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)bucket);
       const unsigned long long same = __ballot(bucket == b0);
       const bool shared = __popcll(same) >= 8 && bucket == b0;
@@ -203,7 +213,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_count(PartArgs a) {
     const long long l = 4 * n4 + threadIdx.x;
     if (l > 0 && a.order_id[l - 1] > a.order_id[l]) ++descents;
     const uint32_t idx = (uint32_t)a.order_id[4 * n4 + threadIdx.x] - (uint32_t)a.base;
-    if (idx < (uint32_t)a.n_orders) __hip_atomic_fetch_add(&s_cnt[idx >> kPartShift], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (idx < (uint32_t)a.n_orders) __hip_atomic_fetch_add(&s_cnt[idx >> a.shift], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else st |= kStOrderRange;
   }
   if (st) atomicOr(a.status, st);
@@ -222,7 +232,10 @@ __global__ void __launch_bounds__(kPartThreads) k_part_count(PartArgs a) {
 // ---- offsets and cursors (one workgroup; two buckets per thread) -----------------------------------
 __global__ void __launch_bounds__(kPartThreads) k_part_scan(PartArgs a) {
   __shared__ unsigned long long s_w[kPartWaves];
-  if (part_skip(a)) return;
+  if (part_skip(a)) {                                       // this path does nothing in this call: say so
+    if (threadIdx.x == 0) *a.mode = 0ull;
+    return;
+  }
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long c0 = 2 * tid < a.n_buckets ? a.counts[2 * tid] : 0ull;
   const unsigned long long c1 = 2 * tid + 1 < a.n_buckets ? a.counts[2 * tid + 1] : 0ull;
@@ -281,6 +294,9 @@ __device__ __forceinline__ void part_write_round(const uint32_t* s_start, const 
 
 // ---- pass A: lines -> (order index, value) records in 32 coarse bins; stock deltas --------------------
 // LDS: [price int32 p_pad][histogram p_pad][counters 36][start 36][gbase 34 x 8][records 4096 x 8][bin 4096 x 2]
+// kLife: the lifecycle columns are looked at (line prices, order states); a template parameter so that the plain
+// kernel keeps its registers and its loop.
+template <bool kLife>
 __global__ void __launch_bounds__(kPartThreads) k_part_scatter_a(PartArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (part_skip_scatter_a(a)) return;
@@ -298,14 +314,20 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_a(PartArgs a) {
   __syncthreads();
   const uint32_t P = (uint32_t)a.n_products;
   const long long n_rounds = (a.n_lines + kPartRound - 1) / kPartRound;
+  const unsigned long long val_mask = part_val_mask(a);
+  const int coarse_shift = a.shift + kPartCoarseShift;
   uint32_t st = 0;
 
-  auto load_round = [&](long long r, int (&ids)[4], int (&prs)[4], int (&qs)[4]) {
+  const bool snapped = kLife && a.line_price != nullptr;   // uniform
+  const bool stated = kLife && a.order_state != nullptr;
+  const uint32_t top = (uint32_t)a.n_orders - 1u;           // (n_orders > 0 whenever there are lines)
+  auto load_round = [&](long long r, int (&ids)[4], int (&prs)[4], int (&qs)[4], long long (&lp)[4]) {
     const long long l0 = r * kPartRound + (long long)tid * 4;
     if (l0 + 4 <= a.n_lines) {
       load_lines<4>(a.order_id + l0, ids);
       load_lines<4>(a.product_idx + l0, prs);
       load_lines<4>(a.qty + l0, qs);
+      if (snapped) load_prices<4>(a.line_price + l0, lp);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -313,19 +335,22 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_a(PartArgs a) {
         ids[i] = in ? a.order_id[l0 + i] : a.base - 1;      // outside the order range: dropped below, not reported
         prs[i] = in ? a.product_idx[l0 + i] : -1;
         qs[i] = in ? a.qty[l0 + i] : 0;
+        if (kLife) lp[i] = (snapped && in) ? a.line_price[l0 + i] : 0ll;
       }
     }
   };
 
   long long r = blockIdx.x;
   int nid[4], npr[4], nq[4];
-  if (r < n_rounds) load_round(r, nid, npr, nq);
+  long long nlp[4] = {0, 0, 0, 0};
+  if (r < n_rounds) load_round(r, nid, npr, nq, nlp);
   for (; r < n_rounds; r += gridDim.x) {
     int ids[4], prs[4], qs[4];
+    long long lps[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ids[i] = nid[i]; prs[i] = npr[i]; qs[i] = nq[i]; }
+    for (int i = 0; i < 4; ++i) { ids[i] = nid[i]; prs[i] = npr[i]; qs[i] = nq[i]; lps[i] = nlp[i]; }
     const long long l0 = r * kPartRound + (long long)tid * 4;
-    if (r + gridDim.x < n_rounds) load_round(r + gridDim.x, nid, npr, nq);     // in flight while this round is binned
+    if (r + gridDim.x < n_rounds) load_round(r + gridDim.x, nid, npr, nq, nlp);     // in flight while this round is binned
     uint32_t bin[4], pos[4];
     unsigned long long rec[4];
     bool wide = false;
@@ -334,16 +359,21 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_a(PartArgs a) {
       const uint32_t idx = (uint32_t)ids[i] - (uint32_t)a.base;
       const bool ok = idx < (uint32_t)a.n_orders;
       if (!ok && l0 + i < a.n_lines) st |= kStOrderRange;
-      bin[i] = ok ? (idx >> (kPartShift + kPartCoarseShift)) : (uint32_t)kPartCoarse;
+      bin[i] = ok ? (idx >> coarse_shift) : (uint32_t)kPartCoarse;
       const uint32_t pi = min((uint32_t)prs[i], P);
-      const unsigned long long val = (unsigned long long)((long long)s_price[pi] * (long long)qs[i]);
-      wide |= ok && val > kPartValMask;
-      rec[i] = ((unsigned long long)idx << kPartValBits) | (val & kPartValMask);
+      // the line's own price when the column is there (an unknown product still adds nothing), else the table's
+      const long long price = snapped ? (pi < P ? lps[i] : 0ll) : (long long)s_price[pi];
+      const unsigned long long val = (unsigned long long)(price * (long long)qs[i]);
+      wide |= ok && val > val_mask;
+      rec[i] = ((unsigned long long)idx << a.val_bits) | (val & val_mask);
       if (hist) {
-        if ((uint32_t)qs[i] < a.q_small)
-          __hip_atomic_fetch_add(&s_hist[pi], (uint32_t)qs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // the lines of an order that does not count leave the stock deltas (its total is kept)
+        int qh = qs[i];
+        if (stated) qh = (a.order_state[min(idx, top)] & 1u) ? qs[i] : 0;
+        if ((uint32_t)qh < a.q_small)
+          __hip_atomic_fetch_add(&s_hist[pi], (uint32_t)qh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else if (pi < P)
-          atomicAdd(&a.prod_carry[pi], (unsigned long long)(long long)qs[i]);
+          atomicAdd(&a.prod_carry[pi], (unsigned long long)(long long)qh);
       }
     }
     part_rank_many<4>(s_cnt, bin, lane, pos);
@@ -395,6 +425,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_b(PartArgs a) {
   __syncthreads();
   const long long n_rec = (long long)a.bucket_off[kPartMaxBuckets];
   const long long n_rounds = (n_rec + kPartRoundB - 1) / kPartRoundB;
+  const int bucket_bits = a.val_bits + a.shift;             // a record's bucket number stands above these
 
   // A round is four quarters of 2048 records; thread t holds records 2t, 2t + 1 of each quarter: one 16-byte load
   // per quarter, contiguous over the workgroup.  (Four consecutive records per thread would make every load cover
@@ -429,7 +460,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_b(PartArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const long long e = r * kPartRoundB + (long long)(i >> 1) * kQuarter + (long long)tid * 2 + (i & 1);
-      bin[i] = e < n_rec ? (uint32_t)(rec[i] >> (kPartValBits + kPartShift)) : (uint32_t)kPartMaxBuckets;
+      bin[i] = e < n_rec ? (uint32_t)(rec[i] >> bucket_bits) : (uint32_t)kPartMaxBuckets;
     }
     part_rank_many<8>(s_cnt, bin, lane, pos);
     __syncthreads();
@@ -461,13 +492,19 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_b(PartArgs a) {
   }
 }
 
-// ---- one workgroup per bucket: the totals of its 16384 orders ----------------------------------------
+// ---- one workgroup per 16384 orders: their totals ----------------------------------------------------
+// A bucket holds 2^shift orders; its 2^(shift - 14) workgroups (consecutive in the grid) all read the bucket's
+// records and each keeps the ones of its own 16384 orders.
 __global__ void __launch_bounds__(kPartThreads) k_part_reduce(PartArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (part_skip_moving(a)) return;
   unsigned long long* s_tab = reinterpret_cast<unsigned long long*>(smem);   // [16384]
   const int tid = (int)threadIdx.x;
-  const int b = (int)blockIdx.x;
+  const int part_bits = a.shift - kPartShift;                // 0, 1 or 2
+  const int b = (int)(blockIdx.x >> part_bits);
+  const uint32_t part = blockIdx.x & ((1u << part_bits) - 1u);
+  const unsigned long long val_mask = part_val_mask(a);
+  const uint32_t in_bucket = (1u << a.shift) - 1u;
   for (int i = tid * 2; i < kPartBucket; i += kPartThreads * 2) *reinterpret_cast<uint4*>(s_tab + i) = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   const long long lo = (long long)a.bucket_off[b], hi = (long long)a.bucket_off[b + 1];
@@ -489,20 +526,31 @@ __global__ void __launch_bounds__(kPartThreads) k_part_reduce(PartArgs a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const unsigned long long r = (unsigned long long)rec[k][j];
-        if (ek + j >= lo && ek + j < hi)
-          __hip_atomic_fetch_add(&s_tab[(r >> kPartValBits) & (kPartBucket - 1)], r & kPartValMask, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t cell = ((uint32_t)(r >> a.val_bits) & in_bucket) - part * (uint32_t)kPartBucket;   // < 16384: this part's
+        if (ek + j >= lo && ek + j < hi && cell < (uint32_t)kPartBucket)
+          __hip_atomic_fetch_add(&s_tab[cell], r & val_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
   __syncthreads();
-  const long long o0 = (long long)b * kPartBucket;
-  long long n = (long long)a.n_orders - o0;
+  const long long o0 = ((long long)b << a.shift) + (long long)part * kPartBucket;
+  long long n = (long long)a.n_orders - o0;                  // (may be <= 0 for the last bucket's later parts)
   if (n > kPartBucket) n = kPartBucket;
   // o0 is a multiple of 16384 and order_total is 16-byte aligned: two totals per store
+  if (a.order_descuento) {                                   // uniform: the totals are stored net of venta.Descuento
+    for (long long i = (long long)tid * 2; i + 1 < n; i += kPartThreads * 2) {
+      longlong2 t;
+      t.x = net_total((long long)s_tab[i], (uint32_t)(o0 + i), a.order_descuento, a.descuento_mode);
+      t.y = net_total((long long)s_tab[i + 1], (uint32_t)(o0 + i + 1), a.order_descuento, a.descuento_mode);
+      *reinterpret_cast<longlong2*>(a.order_total + o0 + i) = t;
+    }
+    if (n > 0 && (n & 1) && tid == 0)
+      a.order_total[o0 + n - 1] = net_total((long long)s_tab[n - 1], (uint32_t)(o0 + n - 1), a.order_descuento, a.descuento_mode);
+    return;
+  }
   for (long long i = (long long)tid * 2; i + 1 < n; i += kPartThreads * 2)
     *reinterpret_cast<uint4*>(a.order_total + o0 + i) = *reinterpret_cast<const uint4*>(s_tab + i);
-  if ((n & 1) && tid == 0) a.order_total[o0 + n - 1] = (int64_t)s_tab[n - 1];
+  if (n > 0 && (n & 1) && tid == 0) a.order_total[o0 + n - 1] = (int64_t)s_tab[n - 1];
 }
 
 }  // namespace acmpc

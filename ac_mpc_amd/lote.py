@@ -218,6 +218,16 @@ class MotorLote:
         modo = _lib.ORDER_AUTO if cualquiera == "auto" else _lib.ORDER_ANY if cualquiera else _lib.ORDER_GROUPED
         self._check(self._lib.acmpc_set_option(self._ctx, _lib.OPT_LINE_ORDER, modo))
 
+    def camino_lineas(self, stream: Optional[int] = None) -> int:
+        """Which way the last call summed rows whose order was not promised (`_lib.PATH_*`): the GPU decides,
+        so this waits for the stream and reads the answer back."""
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        path = C.c_int(0)
+        self._check(self._lib.acmpc_last_line_order_path(self._ctx, stream, C.byref(path)))
+        return int(path.value)
+
     # -- kernel timing --------------------------------------------------------------------------
     def perfilar(self, activo: bool) -> None:
         self._check(self._lib.acmpc_set_profiling(self._ctx, 1 if activo else 0))

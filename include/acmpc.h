@@ -252,7 +252,9 @@ int acmpc_status(acmpc_ctx* ctx, void* hip_stream, uint32_t* flags);
  *                                  partition by order id) and summed there, rows near it are summed with one
  *                                  64-bit global atomic per run of equal ids, and rows whose ids never go down
  *                                  go through the grouped pass after one look at the ids.  1.5 (grouped after
- *                                  all) to 3.7 times (no order at all) the grouped time.
+ *                                  all) to 3.7 times (no order at all) the grouped time.  The lifecycle columns
+ *                                  take the same route; so do up to 2^27 orders (beyond 2^25 the buckets hold
+ *                                  32768 or 65536 orders and are read twice or four times by the last pass).
  *   ACMPC_ORDER_AUTO               the grouped pass runs first; only if it meets a descending order id
  *                                  are the order totals redone by the any-order pass (decided on the
  *                                  device, without a host round trip).  Costs a few near-empty kernel
@@ -265,6 +267,25 @@ int acmpc_status(acmpc_ctx* ctx, void* hip_stream, uint32_t* flags);
 #define ACMPC_ORDER_ANY        1
 #define ACMPC_ORDER_AUTO       2
 int acmpc_set_option(acmpc_ctx* ctx, int option, int64_t value);
+
+/*
+ * Which way the last aggregate call of this context summed rows whose order was not promised (ACMPC_ORDER_ANY, or
+ * ACMPC_ORDER_AUTO after the grouped pass met a descending id).  The device decides, so the answer is read back
+ * from it: the call waits for hip_stream.  No counterpart in the reference (diagnostics and tests).
+ *   ACMPC_PATH_NONE     the order-restoring path was not part of the call (grouped mode; or its limits: both product
+ *                       tables in LDS with prices below 2^31 cents, at most 2^27 orders)
+ *   ACMPC_PATH_ATOMIC   rows near enough to grouped: one 64-bit atomic per run of equal ids (also what is reported
+ *                       when the path was queued but left at once: ACMPC_ORDER_AUTO on rows that were grouped)
+ *   ACMPC_PATH_MOVED    rows moved next to their order's neighbourhood and summed there
+ *   ACMPC_PATH_MOVED_STOCK  a line's value did not fit a record: stock deltas from the moving pass, totals by atomics
+ *   ACMPC_PATH_GROUPED  the ids never went down: the grouped pass summed them
+ */
+#define ACMPC_PATH_NONE        -1
+#define ACMPC_PATH_ATOMIC       0
+#define ACMPC_PATH_MOVED        1
+#define ACMPC_PATH_MOVED_STOCK  2
+#define ACMPC_PATH_GROUPED      3
+int acmpc_last_line_order_path(acmpc_ctx* ctx, void* hip_stream, int* path);
 
 /*
  * Kernel timing.  With profiling enabled every acmpc_aggregate_device() call

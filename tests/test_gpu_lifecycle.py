@@ -22,11 +22,11 @@ def _run_host(motor, d, n_customers, cols, mode):
                          descuento=cols["order_descuento"], descuento_porcentaje=bool(mode))
 
 
-def _expect(oracle, d, n_customers, price, cols, mode):
+def _expect(oracle, d, n_customers, price, cols, mode, any_order=False):
     tot, pq, ct, flags = oracle.aggregate_lifecycle(d["order_id"], d["product_idx"], d["qty"], d["order_customer"],
                                                     d["order_id_base"], n_customers, price, cols["line_price"],
                                                     cols["order_state"], cols["order_descuento"], mode)
-    assert flags == 0
+    assert flags & ~(2 if any_order else 0) == 0          # (the oracle only notes that the ids are unsorted)
     return tot, pq, ct
 
 
@@ -87,6 +87,51 @@ def test_table_modes_and_any_order(oracle, big_tables, any_order, nuevo_motor):
     m.orden_lineas(any_order)
     got = _run_host(m, d, c, cols, 1)
     assert all(np.array_equal(g, e) for g, e in zip(got, exp))
+    # shuffled rows with every lifecycle column are moved next to their orders (the order-restoring path), not
+    # summed with one atomic per line; product tables too large for LDS keep the atomic kernel
+    from ac_mpc_amd import _lib
+    assert m.camino_lineas() == (_lib.PATH_NONE if (big_tables or not any_order) else _lib.PATH_MOVED)
+
+
+@pytest.mark.parametrize("mask", ["p--", "-s-", "--d", "psd"])
+@pytest.mark.parametrize("orden", [True, "auto"])
+def test_every_column_on_every_way_through_rows_in_any_order(oracle, nuevo_motor, mask, orden):
+    """The device picks one of four ways to sum rows whose order is not promised; each must honour the lifecycle
+    columns: rows in no order (moved), rows with a few swapped neighbours (one atomic per run), values that do not
+    fit a record (stock deltas from the moving pass, totals by atomics) and rows that were grouped after all."""
+    from ac_mpc_amd import _lib
+    n, p, c = 400_003, 700, 3_000
+    d = oracle.synth(n, p, c, qty_mode=1)
+    price = oracle.synth_prices(p)
+    m = nuevo_motor
+    m.cargar_productos(price)
+    m.orden_lineas(orden)
+    rng = np.random.default_rng(17)
+    for way in ("shuffled", "swapped", "wide", "grouped"):
+        cols = lc.columns(d, 31, mask)
+        dd = dict(d)
+        perm = np.arange(n)
+        if way in ("shuffled", "wide"):
+            perm = rng.permutation(n)
+        elif way == "swapped":
+            k = rng.choice(n - 1, 50, replace=False)
+            perm[k], perm[k + 1] = perm[k + 1].copy(), perm[k].copy()
+        for key in ("order_id", "product_idx", "qty"):
+            dd[key] = d[key][perm]
+        if cols["line_price"] is not None:
+            cols["line_price"] = cols["line_price"][perm]
+        if way == "wide":                                   # one line worth more than 2^39 cents (a quantity of 2^30)
+            dd["qty"] = dd["qty"].copy()
+            dd["qty"][n // 2] = 1 << 30
+        for mode in (0, 1):
+            exp = _expect(oracle, dd, c, price, cols, mode, any_order=True)
+            got = _run_host(m, dd, c, cols, mode)
+            for g, e, name in zip(got, exp, ("order_total", "product_qty", "customer_total")):
+                assert np.array_equal(g, e), (way, name, mode)
+            path = m.camino_lineas()
+            if orden is True:
+                assert path == {"shuffled": _lib.PATH_MOVED, "swapped": _lib.PATH_ATOMIC, "wide": _lib.PATH_MOVED_STOCK,
+                                "grouped": _lib.PATH_GROUPED}[way], (way, path)
 
 
 def test_orders_without_lines_still_get_their_discount(nuevo_motor):

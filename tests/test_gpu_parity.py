@@ -537,6 +537,60 @@ def test_any_line_order(motor, oracle, n, p, c, mode):
     _check_any_order(motor, oracle, oid[perm], pidx[perm], qty[perm], d["order_customer"], 5, c, oracle.synth_prices(p))
 
 
+@pytest.mark.parametrize("shift", [15, 16])
+@pytest.mark.parametrize("n", [70_001, 3_000_017])
+def test_any_line_order_with_larger_buckets(monkeypatch, oracle, shift, n):
+    """Beyond 2^25 orders the buckets of the order-restoring path hold 32768 or 65536 orders and the last pass
+    reads every bucket with two or four workgroups, each keeping its own 16384 orders.  The developer switch puts
+    small inputs through the same code: last buckets that are partly filled, parts without any order."""
+    from ac_mpc_amd import MotorLote, _lib
+    monkeypatch.setenv("ACMPC_PART_SHIFT", str(shift))
+    m = MotorLote(0)
+    try:
+        p, c = 3_000, 40_000
+        d = oracle.synth(n, p, c, zipf=1, qty_mode=1)
+        perm = np.random.default_rng(shift).permutation(n)
+        _check_any_order(m, oracle, d["order_id"][perm], d["product_idx"][perm], d["qty"][perm], d["order_customer"], 5, c,
+                         oracle.synth_prices(p))
+        m.orden_lineas(True)
+        m.agregar(d["order_id"][perm], d["product_idx"][perm], d["qty"][perm], d["order_customer"], 5, c)
+        assert m.camino_lineas() == _lib.PATH_MOVED
+    finally:
+        m.cerrar()
+
+
+def test_any_line_order_beyond_2_to_the_25_orders(motor, oracle):
+    """36 M orders (144 M lines) in no order at all, device resident: more than the 2^25 orders that buckets of
+    16384 reach, so the path runs with buckets of 32768 orders; all three outputs equal the oracle's."""
+    import torch
+    from ac_mpc_amd import _lib
+    n, p, c = 144_000_000, 10_000, 100_000
+    ds = sintetico.generar(motor, n, p, c, zipf=True, qty_mode=0)
+    assert ds.n_orders > (1 << 25)
+    dev = ds.order_id.device
+    oid_h, pidx_h, qty_h = (t.cpu().numpy() for t in (ds.order_id, ds.product_idx, ds.qty))
+    etot, epq, ect, flags = oracle.aggregate(oid_h, pidx_h, qty_h, ds.order_customer.cpu().numpy(), ds.order_id_base, c,
+                                             ds.price_cents, threads=8)
+    assert flags == 0
+    g = torch.Generator(device=dev); g.manual_seed(41)
+    perm = torch.randperm(n, device=dev, generator=g)
+    oid, pidx, qty = ds.order_id[perm].contiguous(), ds.product_idx[perm].contiguous(), ds.qty[perm].contiguous()
+    del perm
+    tot = torch.full((ds.n_orders,), -7, dtype=torch.int64, device=dev)
+    pq = torch.full((p,), -7, dtype=torch.int64, device=dev)
+    ct = torch.full((c,), -7, dtype=torch.int64, device=dev)
+    motor.orden_lineas(True)
+    try:
+        motor.agregar_device(oid, pidx, qty, ds.order_customer, ds.order_id_base, c, tot, pq, ct)
+        assert motor.estado() == 0
+        assert motor.camino_lineas() == _lib.PATH_MOVED
+    finally:
+        motor.orden_lineas(False)
+    np.testing.assert_array_equal(tot.cpu().numpy(), etot)
+    np.testing.assert_array_equal(pq.cpu().numpy(), epq)
+    np.testing.assert_array_equal(ct.cpu().numpy(), ect)
+
+
 def test_any_line_order_rough_values(motor, oracle):
     v = np.load(os.path.join(GOLDEN, "synth_5k_rough.npz"))
     rng = np.random.default_rng(29)

@@ -29,4 +29,27 @@ def inter(t):
     u = t.clone(); u[:k] = t[:k].view(-1, 2, 4).flip(1).reshape(-1); return u
 run(inter(ds.order_id), inter(ds.product_idx), inter(ds.qty), "4-row blocks swapped, any-order", True)
 perm = torch.randperm(n, device=dev)
-run(ds.order_id[perm], ds.product_idx[perm], ds.qty[perm], "fully shuffled rows, any-order", True)
+so, sp, sq = ds.order_id[perm], ds.product_idx[perm], ds.qty[perm]
+run(so, sp, sq, "fully shuffled rows, any-order", True)
+# the same shuffled rows with every lifecycle column (line prices, order states, discounts in per cent)
+g = torch.Generator(device=dev); g.manual_seed(11)
+lp = torch.randint(1, 500_000, (n,), dtype=torch.int64, device=dev, generator=g)
+stt = (torch.randint(0, 10, (ds.n_orders,), device=dev, generator=g) != 0).to(torch.uint8)
+de = torch.randint(0, 101, (ds.n_orders,), dtype=torch.int32, device=dev, generator=g)
+def run_life(label, **cols):
+    m.orden_lineas(True)
+    call = lambda: m.agregar_device(so, sp, sq, ds.order_customer, ds.order_id_base, 100_000, tot, pq, ct,
+                                    descuento_porcentaje=True, **cols)
+    for _ in range(2):
+        call()
+    m.estado()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        call()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{label:34s} {e0.elapsed_time(e1) / 5:8.3f} ms/step  path {m.camino_lineas()}")
+run_life("shuffled + line prices", precio_linea=lp)
+run_life("shuffled + order states", estado_pedido=stt)
+run_life("shuffled + discounts", descuento=de)
+run_life("shuffled + all three columns", precio_linea=lp, estado_pedido=stt, descuento=de)
