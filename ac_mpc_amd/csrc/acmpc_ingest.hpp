@@ -55,7 +55,8 @@ struct IngestArgs {
   unsigned long long* n_malformed;    // device scalar
   uint32_t* status;
   int32_t ablate;                     // developer switch for timing experiments (0 in production): 1 no field
-                                      // conversion, 2 no dictionary, 4 no automaton, 8 no stores, 64 no look-back
+                                      // conversion, 2 no dictionary, 4 no automaton, 8 no stores, 16 no line starts
+                                      // looked at, 32 no newline search, 64 no look-back
 };
 
 __device__ __forceinline__ bool ing_digit(uint32_t c) { return c - '0' < 10u; }
@@ -668,6 +669,7 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
           w[4 * j] = x.x; w[4 * j + 1] = x.y; w[4 * j + 2] = x.z; w[4 * j + 3] = x.w;
         }
         nl = ing_newline_mask(w);
+        if (ablate & 32) nl = ~0ull;
       }
       // line starts of the slice (the byte in front is a newline, or the text starts here), then the data
       // rows among them by their first one or two bytes; a statement line hands out the position of its '('
@@ -675,6 +677,7 @@ __global__ void __launch_bounds__(kIngThreads) __attribute__((amdgpu_waves_per_e
       const int64_t left = a.n_bytes - (c_next * kIngChunk + o);      // bytes of text from this thread's first byte on
       unsigned long long smask = ((nl << 1) | (t[o - 1] == (unsigned char)'\n' ? 1ull : 0ull)) & ((1ull << kIngPerThread) - 1ull);
       if (left < kIngPerThread) smask = left > 0 ? (smask & ((1ull << left) - 1ull)) : 0ull;
+      if (ablate & 16) smask = 0ull;
       nxt.rows = 0; nxt.stmt_at = 0;
       int n_stmt = 0;
       for (unsigned long long m = smask; m; m &= m - 1ull) {
