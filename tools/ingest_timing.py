@@ -12,7 +12,7 @@ p = 10_000
 codes = [ic.code_of(i) for i in range(p)]
 ingesta.cargar_codigos(m, codes)
 d = orc.synth(1_000_000, p, 100_000)
-for style in ("dump", "csv", "statements"):
+for style in os.environ.get("ACMPC_ING_STYLES", "dump,csv,statements").split(","):
     block = ic.render(d["order_id"].tolist(), d["product_idx"].tolist(), d["qty"].tolist(), style)
     dev = torch.device("cuda", 0)
     tb = torch.frombuffer(bytearray(block), dtype=torch.uint8).to(dev)
