@@ -97,6 +97,7 @@ struct acmpc_ctx {
   // order-restoring path for rows in any order: two sets of (order index, value) records, counters
   DevBuf<unsigned long long> d_part_rec[2];   // records of the order-restoring path after its two scatter passes
   DevBuf<unsigned long long> d_part_meta;
+  DevBuf<uint32_t> d_part_state_bits;         // one bit per order (lifecycle: order states for rows in any order)
   int partition = 1;                // 0: rows in any order always go through the atomic kernel (ACMPC_PARTITION=0)
   bool part_ran = false;            // the last aggregate call queued the order-restoring path (its mode word says what it did)
   unsigned long long* d_part_mode = nullptr;   // that word (inside d_part_meta)
@@ -479,6 +480,13 @@ int launch_partition(acmpc_ctx* ctx, PartArgs& a, int blocks, hipStream_t st) {
   a.n_buckets = (int32_t)(((int64_t)a.n_orders + ((int64_t)1 << a.shift) - 1) >> a.shift);
   HIPCHK(ctx, hipMemsetAsync(a.counts, 0, (size_t)kPartMaxBuckets * 8, st));
   HIPCHK(ctx, hipMemsetAsync(a.changes, 0, 16, st));     // changes and descents
+  a.state_bits = nullptr;
+  if (a.order_state && !a.totals_only) {                 // (only the stock deltas look at the states)
+    const size_t n_words = ((size_t)a.n_orders + 31) / 32;
+    if ((rc = ensure(ctx, ctx->d_part_state_bits, n_words))) return rc;
+    a.state_bits = ctx->d_part_state_bits.p;
+    hipLaunchKernelGGL(k_part_state_bits, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n_words + 255) / 256, (size_t)ctx->n_cu * 8))), dim3(256), 0, st, a);
+  }
   hipLaunchKernelGGL(k_part_count, dim3(blocks), dim3(kPartThreads), 0, st, a);
   hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(kPartThreads), 0, st, a);
   const size_t lds_a = (size_t)ctx->p_pad * 8 + kPartLdsA;
@@ -1002,7 +1010,7 @@ ACMPC_API void acmpc_destroy(acmpc_ctx* ctx) {
   release(ctx->s_synth_off); release(ctx->s_synth_cdf);
   release(ctx->d_edge_idx); release(ctx->d_edge_total);
   release(ctx->d_part_rec[0]); release(ctx->d_part_rec[1]);
-  release(ctx->d_part_meta);
+  release(ctx->d_part_meta); release(ctx->d_part_state_bits);
   release(ctx->d_dict); release(ctx->d_dict_disp); release(ctx->d_codes); release(ctx->d_chunk_rows); release(ctx->d_ing_tables);
   release(ctx->s_text); release(ctx->d_chunk_bytes); release(ctx->s_emit_value);
   release(ctx->s_line_price); release(ctx->s_order_state); release(ctx->s_order_descuento);

@@ -72,6 +72,7 @@ struct PartArgs {
   // counts towards the stock deltas (bit 0 of its state), and venta.Descuento, taken off where the reduce writes
   const long long* line_price;        // [n_lines]
   const unsigned char* order_state;   // [n_orders]
+  uint32_t* state_bits;               // [ceil(n_orders / 32)] bit 0 of every order's state, packed (filled by k_part_state_bits)
   const int32_t* order_descuento;     // [n_orders]
   int32_t descuento_mode;
   unsigned long long* changes;        // zero on entry of k_part_count
@@ -137,6 +138,32 @@ __device__ __forceinline__ void part_rank_many(uint32_t* s_cnt, const uint32_t (
     if (lane == leader) base = __hip_atomic_fetch_add(&s_cnt[key[i]], (uint32_t)__popcll(m[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     base = (uint32_t)__shfl((int)base, leader);
     pos[i] = base + (uint32_t)__popcll(below);
+  }
+}
+
+// ---- order states, one bit per order ---------------------------------------------------------------
+// Pass A needs the state of every line's order, and rows in any order ask for them at random: from the byte column
+// (25 MB for 25 M orders) every look is a miss of the XCD's L2; one bit per order is 3 MB and stays there.
+__global__ void __launch_bounds__(256) k_part_state_bits(PartArgs a) {
+  if (part_skip(a)) return;
+  const long long n_words = ((long long)a.n_orders + 31) / 32;
+  for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (long long)gridDim.x * blockDim.x) {
+    const long long o0 = w * 32;
+    uint32_t bits = 0u;
+    if (o0 + 32 <= (long long)a.n_orders) {
+      const uint4 x = *reinterpret_cast<const uint4*>(a.order_state + o0);        // (the column is 16-byte aligned)
+      const uint4 y = *reinterpret_cast<const uint4*>(a.order_state + o0 + 16);
+      const uint32_t v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t t = v[k] & 0x01010101u;                                    // bit 0 of four states
+        bits |= ((t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xfu) << (4 * k);
+      }
+    } else {
+      for (int k = 0; k < 32; ++k)
+        if (o0 + k < (long long)a.n_orders && (a.order_state[o0 + k] & 1u)) bits |= 1u << k;
+    }
+    a.state_bits[w] = bits;
   }
 }
 
@@ -319,7 +346,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_a(PartArgs a) {
   uint32_t st = 0;
 
   const bool snapped = kLife && a.line_price != nullptr;   // uniform
-  const bool stated = kLife && a.order_state != nullptr;
+  const bool stated = kLife && a.state_bits != nullptr;
   const uint32_t top = (uint32_t)a.n_orders - 1u;           // (n_orders > 0 whenever there are lines)
   auto load_round = [&](long long r, int (&ids)[4], int (&prs)[4], int (&qs)[4], long long (&lp)[4]) {
     const long long l0 = r * kPartRound + (long long)tid * 4;
@@ -369,7 +396,7 @@ __global__ void __launch_bounds__(kPartThreads) k_part_scatter_a(PartArgs a) {
       if (hist) {
         // the lines of an order that does not count leave the stock deltas (its total is kept)
         int qh = qs[i];
-        if (stated) qh = (a.order_state[min(idx, top)] & 1u) ? qs[i] : 0;
+        if (stated) { const uint32_t o = min(idx, top); qh = ((a.state_bits[o >> 5] >> (o & 31u)) & 1u) ? qs[i] : 0; }
         if ((uint32_t)qh < a.q_small)
           __hip_atomic_fetch_add(&s_hist[pi], (uint32_t)qh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else if (pi < P)
