@@ -137,9 +137,9 @@ struct acmpc_ctx {
   int k1_blocks_per_cu = 1;
   int k1_lpl = 4;
   int k2_threads = 1024;
-  int k1_burst = 2;             // tiles between synchronised output bursts of k_lines (0 = off)
+  int k1_burst = 10;            // tiles between synchronised output bursts of k_lines (0 = off)
   int k1_tpw = 0;               // developer switch: at least this many tiles per wave in k_lines (ACMPC_K1_TPW)
-  int k1_stage = 0;             // developer switch: staging slots per wave in k_lines (ACMPC_K1_STAGE; 0 = 512)
+  int k1_stage = 0;             // developer switch: staging slots per wave in k_lines (ACMPC_K1_STAGE; 0 = 1024)
   int k1_cus = 0, k2_cus = 0;   // developer switches: pretend the device has this many CUs (0 = all)
   // developer switches for timing experiments: parts of a kernel are skipped and its results are WRONG.
   // Read once at init, and only when ACMPC_DEV_ABLATE=1 is set as well.
@@ -279,7 +279,7 @@ int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p, bool line_pr
   p->tile_lines = kWave * p->lpl;
   // besides the tables every wave stages finished order totals: stage_cap slots + 64 scratch slots
   auto stage_bytes = [&](uint32_t cap) {
-    return (size_t)p->waves_per_block * ((cap + kWave) * 8 + (line_prices ? 2048 : 0));
+    return (size_t)p->waves_per_block * ((cap + kWave) * sizeof(StageT) + (line_prices ? 2048 : 0));
   };
   auto fits = [&](size_t table_bytes) { return table_bytes + stage_bytes(kTile) + kLdsReserve <= (size_t)kMaxLds; };
   p->lds_tables = !ctx->force_global_tables && fits(p->lds_bytes);
@@ -307,7 +307,7 @@ int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p, bool line_pr
   if (!p->lds_tables) {
     p->lds_bytes = 0; p->price32 = false; p->price_lds = false; p->hist_lds = false; p->lpl = 4; p->tile_lines = kTile;
   }
-  p->stage_cap = ctx->k1_stage >= kTile ? (uint32_t)ctx->k1_stage : 512;
+  p->stage_cap = ctx->k1_stage >= kTile ? (uint32_t)ctx->k1_stage : 1024;
   while (p->stage_cap > (uint32_t)kTile && p->lds_bytes + stage_bytes(p->stage_cap) + kLdsReserve > (size_t)kMaxLds)
     p->stage_cap >>= 1;
   p->flush_reserve = std::min<uint32_t>((uint32_t)p->tile_lines, p->stage_cap / 2);
@@ -965,7 +965,7 @@ ACMPC_API int acmpc_init(acmpc_ctx** out, int device) {
     ctx->ablate_k2 = env_int("ACMPC_K2_ABLATE", 0);
     ctx->ablate_ing = env_int("ACMPC_ING_ABLATE", 0);
   }
-  ctx->k1_burst = std::max(0, env_int("ACMPC_K1_BURST", 2));
+  ctx->k1_burst = std::max(0, env_int("ACMPC_K1_BURST", 10));
   ctx->k1_cus = env_int("ACMPC_K1_CUS", 0);
   ctx->k1_tpw = env_int("ACMPC_K1_TPW", 0);
   ctx->k1_stage = std::min(env_int("ACMPC_K1_STAGE", 0), 4096);

@@ -214,13 +214,18 @@ struct WaveRun {
   uint32_t buf_base;    // order index (id - base) that staging slot 0 stands for
 };
 
+// A staging slot holds a finished order total as an unsigned 32-bit number: half the LDS of a 64-bit
+// slot, so twice the orders fit between two flushes.  A tile in which a total might not fit (any line
+// value or running sum outside [0, 2^32)) takes the rare path, which writes 64-bit totals directly.
+using StageT = uint32_t;
+
 // Write the finished part of the wave's staging buffer — order indices [buf_base, buf_base + n) —
 // to order_total as contiguous 8-byte stores, and leave the buffer zeroed.  Slots never written
 // belong to orders without lines and flush as 0.
 template <bool kLife = false>
-__device__ __forceinline__ void stage_flush(const LinesArgs& a, long long* s_stage, WaveRun& o, uint32_t n, int lane) {
+__device__ __forceinline__ void stage_flush(const LinesArgs& a, StageT* s_stage, WaveRun& o, uint32_t n, int lane) {
   for (uint32_t k = (uint32_t)lane; k < n; k += kWave) {
-    const long long val = s_stage[k];
+    const long long val = (long long)(unsigned long long)s_stage[k];
     s_stage[k] = 0;
     const uint32_t idx = o.buf_base + k;
     if (idx < (uint32_t)a.n_orders) a.order_total[idx] = kLife ? net_total(val, idx, a.order_descuento, a.descuento_mode) : val;
@@ -241,7 +246,7 @@ __device__ __forceinline__ void stage_flush(const LinesArgs& a, long long* s_sta
 // memory, and waiting for a scratch load also waits for the next tile's loads, which were issued first.)
 template <typename PriceT, bool kLdsTables, int LPL, bool kLife = false, bool kPriceGlobal = false, bool kNoHist = false>
 __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_price, uint32_t* s_hist,
-                                           long long* s_stage, const int (&ids)[LPL], const int (&prs)[LPL],
+                                           StageT* s_stage, const int (&ids)[LPL], const int (&prs)[LPL],
                                            const int (&qs)[LPL], int lane, uint32_t lt_lo, uint32_t lt_hi,
                                            WaveRun& o, const int (&qh)[LPL], const long long (&snap)[LPL],
                                            bool snapped) {
@@ -330,7 +335,12 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
 
   const int new_id = __builtin_amdgcn_readlane(ids[LPL - 1], kWave - 1);
   const uint32_t span = ((uint32_t)new_id - (uint32_t)a.base) - o.buf_base;   // slots this tile can touch
-  const bool lane_rare = (kLdsTables && qmax >= a.q_small) || dmin < 0;
+  // Every running sum of this lane lies between 0 and incoming + tot when incoming and the line values
+  // are not negative; all of them below 2^32 is what a staging slot needs.
+  unsigned long long wide = (unsigned long long)incoming | (unsigned long long)(incoming + tot);
+#pragma unroll
+  for (int i = 0; i < LPL; ++i) wide |= (unsigned long long)v[i];
+  const bool lane_rare = (kLdsTables && qmax >= a.q_small) || dmin < 0 || (wide >> 32) != 0ull;
   const unsigned long long rare_mask = __ballot(lane_rare);
   long long run = incoming;
   int pid = prev;
@@ -345,7 +355,7 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
     for (int i = 0; i < LPL; ++i) {
       const uint32_t slot = (uint32_t)pid - off;
       const uint32_t w = min(d[i] ? slot : 0xffffffffu, scratch);
-      s_stage[w] = run;
+      s_stage[w] = (StageT)run;
       run = d[i] ? 0ll : run;
       run += v[i];
       pid = ids[i];
@@ -356,8 +366,8 @@ __device__ __forceinline__ void lines_tile(const LinesArgs& a, const PriceT* s_p
     return;
   }
 
-  // ---- rare path: quantities outside [0, q_small), unsorted ids, or a jump in order ids wider than
-  // the staging buffer.  Empty the buffer, then write this tile's orders (and the ids they skip)
+  // ---- rare path: quantities outside [0, q_small), unsorted ids, a total that may need more than 32
+  // bits, or a jump in order ids wider than the staging buffer.  Empty the buffer, then write this tile's orders (and the ids they skip)
   // directly.
   stage_flush<kLife>(a, s_stage, o, min(((uint32_t)o.id - (uint32_t)a.base) - o.buf_base, a.stage_cap), lane);
   if (kLdsTables && !kNoHist) {
@@ -476,8 +486,8 @@ __global__ void __launch_bounds__(1024) k_lines(LinesArgs a) {
   const size_t tables = kLdsTables ? price_bytes + (kNoHist ? 0 : (size_t)a.p_pad * sizeof(uint32_t)) : 0;
   PriceT* s_price = reinterpret_cast<PriceT*>(smem);
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + price_bytes);
-  long long* s_stage = reinterpret_cast<long long*>(smem + tables) + (size_t)wave * (a.stage_cap + kWave);
-  int4* s_xpose = reinterpret_cast<int4*>(smem + tables + (size_t)waves_per_block * (a.stage_cap + kWave) * 8) + wave * 128;
+  StageT* s_stage = reinterpret_cast<StageT*>(smem + tables) + (size_t)wave * (a.stage_cap + kWave);
+  int4* s_xpose = reinterpret_cast<int4*>(smem + tables + (size_t)waves_per_block * (a.stage_cap + kWave) * sizeof(StageT)) + wave * 128;
 
   for (uint32_t k = (uint32_t)lane; k < a.stage_cap; k += kWave) s_stage[k] = 0;
   if (kLdsTables) {

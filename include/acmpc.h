@@ -156,7 +156,7 @@ int acmpc_aggregate_device(acmpc_ctx* ctx,
  * cells, the records of orders cut by wave boundaries) is a fixed 61.4 MiB array inside the library's
  * code object, of which every GPU the library runs on holds its own copy until the process ends.
  * Limits (ACMPC_E_INVALID beyond them, with the limit in acmpc_last_error): at most 16380 products
- * whose tables fit LDS (about 14.7 k with prices below 2^31 cents, 9.8 k otherwise) and at most
+ * whose tables fit LDS (about 17.7 k with prices below 2^31 cents, 11.8 k otherwise) and at most
  * 131072 customers; ACMPC_ORDER_GROUPED only, no lifecycle columns.  acmpc_set_products must have been
  * called before (it is the call that allocates the price table).
  * Every call on one GPU, from any context of the process, uses that GPU's one array: calls that

@@ -185,6 +185,33 @@ def test_int64_prices_and_wraparound(motor, oracle):
     _check(motor, oracle, d["order_id"], d["product_idx"], qty, d["order_customer"], 5, 500, price)
 
 
+@pytest.mark.parametrize("dear_every", [1, 7, 5000])
+def test_order_totals_either_side_of_2_to_the_32(motor, oracle, dear_every):
+    """Finished totals wait in 32-bit slots; a tile in which one may not fit writes 64-bit totals directly.
+    Prices fit 32 bits and quantities are small, so nothing else sends these tiles the other way: every
+    product dear, one in seven, and one in 5000 (most tiles staged, a few direct, changing back and forth)."""
+    rng = np.random.default_rng(29 + dear_every)
+    n, p = 700_001, 3000
+    d = oracle.synth(n, p, 800, zipf=0, qty_mode=1)
+    price = rng.integers(1, 400_000, p).astype(np.int64)
+    price[::dear_every] = rng.integers(2**30, 2**31 - 1, price[::dear_every].size)
+    tot, _, _ = _check(motor, oracle, d["order_id"], d["product_idx"], d["qty"], d["order_customer"], 5, 800, price)
+    assert (tot >= 2**32).any() and (dear_every == 1 or (tot < 2**32).any())
+
+
+def test_order_totals_of_exactly_2_to_the_32_and_its_neighbours(motor, oracle):
+    price = np.array([2**31 - 1, 1, 2, 300], np.int64)
+    kinds = [([0, 1], [2, 1]), ([0, 2], [2, 1]), ([0, 2, 1], [2, 1, 1]), ([3, 3], [1, 2])]   # 2^32-1, 2^32, 2^32+1, 900
+    rng = np.random.default_rng(31)
+    pick = rng.integers(0, 4, 40_000)
+    pick[:3000] = 3                                        # a stretch of staged tiles first
+    oid = np.concatenate([np.full(len(kinds[k][0]), 5 + i, np.int32) for i, k in enumerate(pick)])
+    pidx = np.concatenate([np.array(kinds[k][0], np.int32) for k in pick])
+    qty = np.concatenate([np.array(kinds[k][1], np.int32) for k in pick])
+    tot, _, _ = _check(motor, oracle, oid, pidx, qty, np.zeros(pick.size, np.int32), 5, 1, price)
+    assert set(np.unique(tot).tolist()) == {900, 2**32 - 1, 2**32, 2**32 + 1}
+
+
 def test_hot_key_quantity_carries(motor, oracle):
     """One product takes every line with quantities near 2^31: the 32-bit LDS partials must carry."""
     n = 600_000

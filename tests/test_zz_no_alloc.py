@@ -107,10 +107,20 @@ def test_limits_are_refused_with_a_message(oracle):
                                                    ds.qty.data_ptr(), ds.n_lines, ds.order_customer.data_ptr(), ds.n_orders,
                                                    ds.order_id_base, 200_000, tot.data_ptr(), pq.data_ptr(), ct.data_ptr(), None)
         assert rc == _lib.E_INVALID and b"131072 customers" in m._lib.acmpc_last_error(m._ctx)
-        # a product table too large for LDS
-        ds = sintetico.generar(m, 5_000, 16_000, 100)
-        pq = torch.empty(16_000, dtype=torch.int64, device=dev)
+        # more products than the fixed workspace holds
+        ds = sintetico.generar(m, 5_000, 20_000, 100)
+        pq = torch.empty(20_000, dtype=torch.int64, device=dev)
         ct = torch.empty(100, dtype=torch.int64, device=dev)
+        tot = torch.empty(ds.n_orders, dtype=torch.int64, device=dev)
+        rc = m._lib.acmpc_aggregate_device_noalloc(m._ctx, ds.order_id.data_ptr(), ds.product_idx.data_ptr(),
+                                                   ds.qty.data_ptr(), ds.n_lines, ds.order_customer.data_ptr(), ds.n_orders,
+                                                   ds.order_id_base, 100, tot.data_ptr(), pq.data_ptr(), ct.data_ptr(), None)
+        assert rc == _lib.E_INVALID and b"16380 products" in m._lib.acmpc_last_error(m._ctx)
+        # a product table within that limit but too large for LDS (prices beyond 32 bits take 12 bytes a product)
+        import numpy as np
+        ds = sintetico.generar(m, 5_000, 14_000, 100)
+        m.cargar_productos(np.full(14_000, 2**33, np.int64))
+        pq = torch.empty(14_000, dtype=torch.int64, device=dev)
         tot = torch.empty(ds.n_orders, dtype=torch.int64, device=dev)
         rc = m._lib.acmpc_aggregate_device_noalloc(m._ctx, ds.order_id.data_ptr(), ds.product_idx.data_ptr(),
                                                    ds.qty.data_ptr(), ds.n_lines, ds.order_customer.data_ptr(), ds.n_orders,
