@@ -260,6 +260,7 @@ struct LinesPlan {
   int lpl;                 // lines per lane per tile (4 or 8)
   int tile_lines;
   uint32_t stage_cap, flush_reserve;
+  int burst;               // tiles between two output bursts of a workgroup (0: none)
   int64_t n_tiles, tiles_per_wave;
   int n_active_waves;
 };
@@ -307,10 +308,14 @@ int plan_lines(const acmpc_ctx* ctx, int64_t n_lines, LinesPlan* p, bool line_pr
   if (!p->lds_tables) {
     p->lds_bytes = 0; p->price32 = false; p->price_lds = false; p->hist_lds = false; p->lpl = 4; p->tile_lines = kTile;
   }
+  // as many staging slots as the tables leave room for (in steps of 64, at most 1024, at least one tile's worth)
   p->stage_cap = ctx->k1_stage >= kTile ? (uint32_t)ctx->k1_stage : 1024;
   while (p->stage_cap > (uint32_t)kTile && p->lds_bytes + stage_bytes(p->stage_cap) + kLdsReserve > (size_t)kMaxLds)
-    p->stage_cap >>= 1;
+    p->stage_cap -= kWave;
   p->flush_reserve = std::min<uint32_t>((uint32_t)p->tile_lines, p->stage_cap / 2);
+  // the workgroup writes its finished totals together every `burst` tiles: as long a stretch as the slots hold at
+  // the 64 orders a tile of the reference's shape closes (a wave that runs out of slots earlier flushes on its own)
+  p->burst = ctx->k1_burst <= 0 ? 0 : std::max(1, std::min(ctx->k1_burst, (int)((p->stage_cap - p->flush_reserve) / 76)));
   p->lds_bytes += stage_bytes(p->stage_cap);
   int bpc = ctx->k1_blocks_per_cu;
   {
@@ -656,7 +661,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.only_if_unsorted = 0;
     a.totals_only = 0;
     a.fill_edges = fused ? 1 : 0;
-    a.burst = (d_line_price || d_state) ? 0 : ctx->k1_burst;     // (measured: no gain with those columns)
+    a.burst = (d_line_price || d_state) ? 0 : lp.burst;          // (measured: no gain with those columns)
     a.order_descuento = desc_in_lines ? d_desc : nullptr;
     a.descuento_mode = d_desc ? life->descuento_mode : 0;
     a.order_state = d_state;
