@@ -63,7 +63,9 @@ def main():
         # bytes the kernel cannot avoid fetching, which decide whether the doubled count is the one to use
         n_lines = int(name.split(",")[0].split("=")[1])
         n_orders = orders_of(out_dir, name, n_lines)
-        floor = {"k_lines<": 12.0 * n_lines, "k_customers": 12.0 * n_orders, "k_tail": 0.0}
+        # (the tail merges the partial sums that the customer pass wrote: it reads at least what that pass wrote)
+        slabs = sum((write.get(kk, {}).get("WRITE_SIZE") or 0.0) * 1024 for kk in fetch if "k_customers" in kk)
+        floor = {"k_lines<": 12.0 * n_lines, "k_customers": 12.0 * n_orders, "k_tail": slabs}
         step, detail = {}, {}
         lower = upper = 0.0
         for kk in fetch:
