@@ -34,7 +34,7 @@ def test_version_and_error_strings():
 
 
 def test_init_rejects_cpu_backend_request():
-    """device < 0 used to mean 'CPU backend' in the survey's sketch; the product has none."""
+    """A negative device is not a request for a CPU backend: the product has none and says so."""
     lib = _lib.load()
     ctx = C.c_void_p()
     rc = lib.acmpc_init(C.byref(ctx), -1)

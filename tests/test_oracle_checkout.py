@@ -49,7 +49,7 @@ def test_checkout_known_answers(case):
     assert [list(r) for r in store.detalle] == case["detalle"]
 
 
-def test_seed_matches_survey_values():
+def test_seed_matches_the_values_of_store_sql():
     s = _seed()
     assert [(r["CodigoProd"], r["Precio"]) for r in s["producto"]] == [("1", "250.00"), ("2", "450.00"), ("3", "1500.00")]
     assert s["cliente"][0]["id_Cliente"] == "7" and s["cliente"][0]["Clave"] == co.md5("123")
