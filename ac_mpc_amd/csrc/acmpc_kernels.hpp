@@ -178,6 +178,13 @@ __device__ __forceinline__ void split_add64(uint32_t* lds_lo, unsigned long long
 // percentage of the gross total, rounded half away from zero to a cent.  Wrapping 64-bit arithmetic.
 __device__ __forceinline__ long long descuento_cents(long long gross, int d, int mode) {
   if (mode == 0) return 100ll * (long long)d;
+  if ((unsigned long long)gross < (1ull << 32) && (uint32_t)d < (1u << 25)) {
+    // the usual sizes: everything fits 32-bit unsigned arithmetic, where a division by 100 is a multiply and a
+    // shift (the 64-bit divisions below are some hundred instructions each); the same value as the general form
+    const uint32_t g = (uint32_t)gross, q = g / 100u, r = g - q * 100u;
+    const uint32_t part = (r * (uint32_t)d + 50u) / 100u;         // r * d < 100 * 2^25
+    return (long long)((unsigned long long)q * (unsigned long long)(uint32_t)d + part);
+  }
   const long long q = gross / 100ll, r = gross - q * 100ll;       // truncating: r has the sign of gross
   const long long x = r * (long long)d;                           // |x| < 100 * 2^31
   const long long part = x >= 0 ? (x + 50ll) / 100ll : -((-x + 50ll) / 100ll);
@@ -224,6 +231,32 @@ using StageT = uint32_t;
 // belong to orders without lines and flush as 0.
 template <bool kLife = false>
 __device__ __forceinline__ void stage_flush(const LinesArgs& a, StageT* s_stage, WaveRun& o, uint32_t n, int lane) {
+  if (kLife && a.order_descuento) {
+    // with discounts: the discounts of six rounds of 64 orders are requested together, then taken off (one
+    // round at a time every store would wait a full trip to memory for its discount)
+    constexpr int kBatch = 6;
+    for (uint32_t k0 = (uint32_t)lane; k0 < n; k0 += kBatch * kWave) {
+      int dsc[kBatch];
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        const uint32_t k = k0 + (uint32_t)j * kWave, idx = o.buf_base + k;
+        dsc[j] = (k < n && idx < (uint32_t)a.n_orders) ? a.order_descuento[idx] : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        const uint32_t k = k0 + (uint32_t)j * kWave, idx = o.buf_base + k;
+        if (k < n) {
+          const long long val = (long long)(unsigned long long)s_stage[k];
+          s_stage[k] = 0;
+          if (idx < (uint32_t)a.n_orders)
+            a.order_total[idx] = (long long)((unsigned long long)val - (unsigned long long)descuento_cents(val, dsc[j], a.descuento_mode));
+          else o.st |= kStOrderRange;
+        }
+      }
+    }
+    o.buf_base += n;
+    return;
+  }
   for (uint32_t k = (uint32_t)lane; k < n; k += kWave) {
     const long long val = (long long)(unsigned long long)s_stage[k];
     s_stage[k] = 0;
