@@ -661,7 +661,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     a.only_if_unsorted = 0;
     a.totals_only = 0;
     a.fill_edges = fused ? 1 : 0;
-    a.burst = (d_line_price || d_state) ? 0 : lp.burst;          // (measured: no gain with those columns)
+    a.burst = lp.burst;
     a.order_descuento = desc_in_lines ? d_desc : nullptr;
     a.descuento_mode = d_desc ? life->descuento_mode : 0;
     a.order_state = d_state;
@@ -713,7 +713,7 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       a.run_if_sorted = pa.mode;
       if (d_line_price) {
         LinesArgs ax = a;                                 // the same launch with the plan that holds the price slices
-        ax.stage_cap = lpx.stage_cap; ax.flush_reserve = lpx.flush_reserve;
+        ax.stage_cap = lpx.stage_cap; ax.flush_reserve = lpx.flush_reserve; ax.burst = lpx.burst;
         rc = launch_lines<int64_t, true, 4, true, true>(ctx, lpx, ax, st);
       }
       else if (life_lines) rc = launch_lines<int32_t, true, 4, true>(ctx, lp, a, st);
