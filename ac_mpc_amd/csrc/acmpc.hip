@@ -603,13 +603,13 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
     ctx->k1_lpl = keep;
   }
   int rc;
-  // The plain grouped path runs in three launches: the record block of k_fixup rides along with the
-  // customer pass, and one tail kernel does the merges.  Everything else keeps the four-launch sequence.
+  // The grouped path (lifecycle columns or not) runs in three launches: the record block of k_fixup rides along
+  // with the customer pass, and one tail kernel does the merges.  Rows in any order keep the four-launch sequence.
   CustPlan cp;
   if (n_orders > 0) plan_customers(ctx, n_orders, n_customers, &cp);
   // (The record block needs some 40 us next to the customer pass: below a few million orders that pass is
   // shorter and the four-launch sequence is quicker.  ACMPC_FUSE=2 forces the fused path for tests.)
-  const bool fused = ctx->fuse && ctx->line_order == ACMPC_ORDER_GROUPED && !life && n_lines > 0 &&
+  const bool fused = ctx->fuse && ctx->line_order == ACMPC_ORDER_GROUPED && n_lines > 0 &&
                      (n_orders >= 4000000 || (ctx->fuse == 2 && n_orders > 0)) &&
                      lp.lds_tables && lp.hist_lds && cp.lds_tables && cp.threads == kFixThreads;
   if (fused && cp.blocks + 8 > ctx->n_cu) plan_customers(ctx, n_orders, n_customers, &cp, 1);   // room for the leading blocks
@@ -850,15 +850,20 @@ int aggregate_device_impl(acmpc_ctx* ctx, const int32_t* d_order_id, const int32
       if ((rc = need(ctx->d_edge_total, w.edge_total, (size_t)2 * kMaxWavesTotal, kNaRecBytes, false))) return rc;
       f.deferred = 1;
       f.order_customer = d_order_customer; f.cust_carry = w.cust_carry; f.n_customers = n_customers;
-      f.edge_idx = w.edge_idx; f.edge_total = w.edge_total;
+      f.edge_idx = w.edge_idx; f.edge_total = w.edge_total; f.order_state = d_state;
       CustFusedArgs fa;
       fa.c = c;
       fa.f = f;
       const size_t lds = std::max(cp.lds_bytes, fix_lds);
-      if ((rc = set_dyn_lds(ctx, k_customers_fused, lds))) return rc;
       // as many leading workgroups as there are CUs the customer pass leaves idle (8 .. 64)
       fa.lead = std::max(8, std::min(64, (ctx->n_cu - cp.blocks) / 8 * 8));
-      hipLaunchKernelGGL(k_customers_fused, dim3(cp.blocks + fa.lead), dim3(cp.threads), lds, st, fa);
+      if (d_state) {
+        if ((rc = set_dyn_lds(ctx, k_customers_fused<true>, lds))) return rc;
+        hipLaunchKernelGGL(k_customers_fused<true>, dim3(cp.blocks + fa.lead), dim3(cp.threads), lds, st, fa);
+      } else {
+        if ((rc = set_dyn_lds(ctx, k_customers_fused<false>, lds))) return rc;
+        hipLaunchKernelGGL(k_customers_fused<false>, dim3(cp.blocks + fa.lead), dim3(cp.threads), lds, st, fa);
+      }
     } else if (cp.lds_tables && d_state) {
       if ((rc = set_dyn_lds(ctx, k_customers<true, true>, cp.lds_bytes))) return rc;
       hipLaunchKernelGGL((k_customers<true, true>), dim3(cp.blocks), dim3(cp.threads), cp.lds_bytes, st, c);

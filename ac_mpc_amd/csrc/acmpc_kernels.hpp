@@ -846,6 +846,7 @@ struct FixArgs {
   int64_t* edge_total;      // [n_rec]
   const int32_t* order_descuento;   // [M] or null: the totals (and the zeros of orders without lines) are stored net of it
   int32_t descuento_mode;
+  const unsigned char* order_state; // [M] or null (deferred mode): an order with bit 0 clear is not in its customer's sum
 };
 
 // Orders without lines, indices [lo, hi): a total of zero (less the order's discount, if any).
@@ -983,12 +984,14 @@ __device__ __forceinline__ void fixup_records(const FixArgs& a, unsigned char* s
         if (idx >= (uint32_t)a.n_orders) st |= kStOrderRange;
         else if (!a.deferred) a.order_total[idx] = net_total(total, idx, a.order_descuento, a.descuento_mode);
         else {
+          const long long net = net_total(total, idx, a.order_descuento, a.descuento_mode);
           const long long seen = a.order_total[idx];           // what the customer pass reads for this order
           const int32_t c = a.order_customer[idx];
-          if ((uint32_t)c < (uint32_t)a.n_customers)             // out of range: flagged by the customer pass
-            atomicAdd(&a.cust_carry[c], (unsigned long long)total - (unsigned long long)seen);
+          const bool counts = !a.order_state || (a.order_state[idx] & 1);   // (a cancelled order: that pass adds nothing)
+          if (counts && (uint32_t)c < (uint32_t)a.n_customers)   // out of range: flagged by the customer pass
+            atomicAdd(&a.cust_carry[c], (unsigned long long)net - (unsigned long long)seen);
           a.edge_idx[i] = idx;
-          a.edge_total[i] = total;
+          a.edge_total[i] = net;
         }
         // Only the step from a wave's tail record (odd i) to the next wave's head record can hide
         // orders without lines; between a wave's own head and tail k_lines wrote everything.
@@ -1209,6 +1212,8 @@ struct CustFusedArgs {
   int32_t lead;             // leading workgroups (a multiple of 8): one record block, lead - 1 merge blocks
 };
 
+// kLife: the order-state column is given (a cancelled order adds nothing to its customer).
+template <bool kLife>
 __global__ void __launch_bounds__(1024) k_customers_fused(CustFusedArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   if ((int)blockIdx.x < a.lead) {
@@ -1221,7 +1226,7 @@ __global__ void __launch_bounds__(1024) k_customers_fused(CustFusedArgs a) {
     }
     return;
   }
-  customers_block<true, false>(a.c, smem, (int)blockIdx.x - a.lead);
+  customers_block<true, kLife>(a.c, smem, (int)blockIdx.x - a.lead);
 }
 
 template <bool kLdsTables, bool kLife>

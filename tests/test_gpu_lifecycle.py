@@ -7,11 +7,23 @@ from tests import lifecycle_cases as lc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def nuevo_motor():
-    """A fresh context per test (options and product tables differ between them), closed afterwards."""
+@pytest.fixture(params=["default", "fused"])
+def nuevo_motor(request):
+    """A fresh context per test (options and product tables differ between them), closed afterwards.  Every case
+    runs twice: with the library's own choice of launch sequence, and with the three-launch sequence forced (by
+    default it is only taken from a few million orders on)."""
+    import os
     from ac_mpc_amd import MotorLote
-    m = MotorLote(0)
+    old = os.environ.get("ACMPC_FUSE")
+    if request.param == "fused":
+        os.environ["ACMPC_FUSE"] = "2"
+    try:
+        m = MotorLote(0)
+    finally:
+        if old is None:
+            os.environ.pop("ACMPC_FUSE", None)
+        else:
+            os.environ["ACMPC_FUSE"] = old
     yield m
     m.cerrar()
 
