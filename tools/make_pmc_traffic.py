@@ -26,7 +26,9 @@ from bench import kernel_source_digest  # noqa: E402
 
 def averages(directory):
     acc = {}
-    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+    # (results of several runs may lie side by side in a directory that was fetched more than once: the newest counts)
+    files = sorted(glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
             if "acmpc::k_" in k and "synth" not in k:
