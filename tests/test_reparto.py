@@ -78,9 +78,11 @@ def _worker(rank, world, port, n_lines, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_merge_equals_unsharded(oracle):
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_merge_equals_unsharded(oracle, world):
+    """One process per shard (two ranks; three, which cut the orders unevenly), the exchange over gloo."""
     import torch.multiprocessing as mp
-    n_lines, world = 30_011, 2
+    n_lines = 30_011
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
